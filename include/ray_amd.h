@@ -1,0 +1,152 @@
+/* ray_amd.h -- C ABI of the MI355X-native ray-intersection + shading path.
+ *
+ * This is the drop-in boundary for the hot path of joblobob/ray. The
+ * reference has no FFI layer of its own: the path sits behind plain C++ free functions and
+ * header-only classes (calc.h, hitPosition.h, shapes.h, camera.h) consumed by RayView. Every entry
+ * point below therefore cites the reference interface it stands in for; the C++ mirror headers
+ * under ray_amd/include/ (same names as the reference's) forward to these functions.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every function returns 0 on success, non-zero on error, and
+ *    never throws. rt_last_error() returns the message for the calling thread's last failure.
+ *  - pointers named d_* are DEVICE pointers (HBM) owned by the caller (rt_malloc, hipMalloc or a
+ *    torch tensor's data_ptr()); everything else is host memory owned by the caller and may be
+ *    freed as soon as the call returns.
+ *  - one context per process and per GPU: rt_init(device) binds the context to a HIP device and
+ *    creates the stream all kernels run on. Calls are blocking unless stated (rt_render_async).
+ *  - the library never falls back to the CPU: without a usable HIP device every compute entry
+ *    point fails with an error.
+ */
+#ifndef RAY_AMD_H
+#define RAY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- primitive / material / light kinds ------------------------------------------------------ */
+enum {
+    RT_PRIM_SPHERE = 0,   /* shapes.h:67  sphere        data = {cx, cy, cz, r}                     */
+    RT_PRIM_XY_RECT = 1,  /* shapes.h:161 rectangle     data = {x0, x1, y0, y1, k}   (plane z = k)  */
+    RT_PRIM_XZ_RECT = 2,  /* shapes.h:226 xz_rect       data = {x0, x1, z0, z1, k}   (plane y = k)  */
+    RT_PRIM_YZ_RECT = 3,  /* shapes.h:292 yz_rect       data = {y0, y1, z0, z1, k}   (plane x = k)  */
+    RT_PRIM_TRIANGLE = 4  /* not in the reference       data = {v0xyz, v1xyz, v2xyz}               */
+};
+enum {
+    RT_MAT_LAMBERTIAN = 0,    /* hitPosition.h:197  rgb = albedo                                   */
+    RT_MAT_METAL = 1,         /* hitPosition.h:222  rgb = albedo, fuzz (already clamped to <= 1)    */
+    RT_MAT_DIELECTRIC = 2,    /* hitPosition.h:246  ir                                             */
+    RT_MAT_DIFFUSE_LIGHT = 3  /* hitPosition.h:290  rgb = emitted colour                            */
+};
+enum {
+    RT_LIGHT_BASE = -1 /* a shape without pdf_value/random (shapes.h:56-62): value 0, dir (1,0,0)   */
+    /* otherwise one of RT_PRIM_SPHERE / RT_PRIM_XY_RECT / RT_PRIM_XZ_RECT                          */
+};
+#define RT_PRIM_STRIDE 9 /* doubles per primitive in RtScene.prim_data                              */
+
+/* Flattened scene: `worldObjects` (std::vector<std::shared_ptr<shape>>, rayview.h:62) in list
+ * order, a `box` (shapes.h:339) expanded in place into its six sides in constructor order
+ * (shapes.h:347-354). Closest-hit semantics are those of hitFromList (hitPosition.cpp:6-22):
+ * the smallest t in [t_min, t_max] wins and among equal t the LATER list entry wins.
+ * float-typed reference fields (sphere centre/radius, triangle vertices) are stored in the double
+ * array exactly (every float is a double); rect bounds are doubles in the reference too.        */
+typedef struct RtScene {
+    int32_t n_prims;
+    const int32_t* prim_kind;  /* [n_prims] RT_PRIM_*                                               */
+    const int32_t* prim_mat;   /* [n_prims] index into the material arrays                          */
+    const int32_t* prim_outer; /* [n_prims] index in the caller's worldObjects list                 */
+    const int32_t* prim_side;  /* [n_prims] 0..5 for a box side, -1 otherwise                       */
+    const double* prim_data;   /* [n_prims][RT_PRIM_STRIDE]                                         */
+    int32_t n_mats;
+    const int32_t* mat_kind;   /* [n_mats] RT_MAT_*                                                 */
+    const float* mat_rgb;      /* [n_mats][3]                                                       */
+    const float* mat_fuzz;     /* [n_mats]                                                          */
+    const double* mat_ir;      /* [n_mats]                                                          */
+    int32_t light_kind;        /* the `lights` shape of calc::ray_color (calc.h:92)                 */
+    double light_data[RT_PRIM_STRIDE];
+    float background[3];       /* calc::ray_color's `background` argument (calc.h:90)               */
+} RtScene;
+
+/* The eight values camera::resetCam derives (camera.h:57-63).                                     */
+typedef struct RtCamera {
+    float origin[3], lower_left_corner[3], horizontal[3], vertical[3];
+    float u[3], v[3], w[3];
+    double lens_radius;
+} RtCamera;
+
+/* flags for rt_render                                                                              */
+#define RT_RENDER_ACCUMULATE 1u /* add to d_accum instead of overwriting it (progressive passes)    */
+#define RT_RENDER_NORMALS 2u    /* drawOnlyColors mode of calc::ray_color (calc.cpp:105-109)        */
+
+/* ---- context ------------------------------------------------------------------------------------ */
+/* Bind this process to HIP device `device` and create the library's stream. Fails (no CPU
+ * fallback) when there is no such device.                                                          */
+int rt_init(int device);
+void rt_shutdown(void);
+const char* rt_last_error(void);
+/* "name|gcnArch|CUs|clockMHz" of the bound device.                                                 */
+int rt_device_info(char* buf, int buflen);
+
+/* device memory helpers for hosts that have no allocator of their own                               */
+int rt_malloc(void** d_ptr, uint64_t bytes);
+int rt_free(void* d_ptr);
+int rt_memcpy_d2h(void* dst, const void* d_src, uint64_t bytes);
+int rt_memcpy_h2d(void* d_dst, const void* src, uint64_t bytes);
+int rt_memset(void* d_ptr, int value, uint64_t bytes);
+int rt_sync(void);
+
+/* ---- scene + camera ------------------------------------------------------------------------------ */
+/* Replaces holding `m_worldObjects` / `worldLights` (rayview.h:62-63) by pointer: validates the
+ * flattened scene, converts it to per-kind structure-of-arrays device buffers and uploads them.
+ * Call again after any mutation (the sphere-Y slider, rayview.cpp:130-134).                        */
+int rt_upload_scene(const RtScene* scene);
+
+/* camera::resetCam (camera.h:32-54) with identical host arithmetic.                                */
+int rt_camera_from_lookat(const float lookfrom[3], const float lookat[3], const float vup[3],
+                          double focus_dist, double vfov, double aspect_ratio, double aperture,
+                          RtCamera* out);
+/* Replaces the by-value `camera cam` member (rayview.h:87).                                        */
+int rt_set_camera(const RtCamera* cam);
+
+/* ---- the hot path -------------------------------------------------------------------------------- */
+/* Primary-ray closest hit for every pixel: camera::get_ray (camera.h:21-30) at the pixel centre,
+ * u = (x + 0.5f) / w, v = (y + 0.5f) / h, then hitFromList(world, ray, 0.001f, inf)
+ * (calc.cpp:99, hitPosition.cpp:6-22). Lens samples (aperture != 0) come from the counter RNG
+ * stream (seed, pixel, sample 0). Outputs, row-major [h][w], any may be NULL:
+ *   d_prim  flattened primitive index of the closest hit, -1 on a miss
+ *   d_t     hit_record::t (double, bit pattern as the reference computes it), 0 on a miss        */
+int rt_primary_hits(int w, int h, uint64_t seed, int32_t* d_prim, double* d_t);
+
+/* hitFromList for caller-supplied rays (hitPosition.h:187-191): n rays, origin/direction as
+ * [n][3] floats. Outputs [n]: prim (-1 = std::nullopt), t, and optionally p[n][3], normal[n][3],
+ * front_face[n] of the hit_record (hitPosition.h:95-109). All pointers are device pointers.      */
+int rt_hit_rays(int64_t n, const float* d_origin, const float* d_dir, double t_min, double t_max,
+                int32_t* d_prim, double* d_t, float* d_p, float* d_normal, uint8_t* d_front);
+
+/* RayView::renderAll (declared rayview.h:32) with the per-pixel contract of renderOneRay
+ * (rayview.cpp:79-84): for every pixel (x, y) and every sample s in [spp_begin, spp_begin +
+ * spp_count):  u = (x + xi) / w, v = (y + xi) / h, sum += calc::ray_color(cam.get_ray(u, v),
+ * background, world, lights, depth). Random numbers come from the counter RNG stream keyed by
+ * (seed, pixel y*w + x, s), so any split of the sample range over calls or GPUs draws the same
+ * numbers. d_accum is [h][w][4] floats (r, g, b sums in sample order; .w = number of samples
+ * accumulated), indexed by the un-mirrored (x, y) of renderOneRay. d_rays (may be NULL) receives
+ * the number of closest-hit scans executed (primary + bounce rays), added atomically.
+ * Pixels outside [y_begin, y_begin + y_count) are not touched (image-tile split).                 */
+int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth,
+              uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
+
+/* calc::rgbPerSamples + RayView::writeToImg (calc.cpp:133-154, rayview.cpp:57-65,86): gamma-2
+ * tonemap of sum / n_samples (n from accum.w when n_samples <= 0), clamp, pack as
+ * QImage::Format_RGB32 (0xffRRGGBB) at the mirrored position (w-1-x, h-1-y).                      */
+int rt_tonemap(int w, int h, const float* d_accum, int n_samples, uint32_t* d_rgb32);
+
+/* Time (ms) the last rt_render / rt_primary_hits / rt_hit_rays kernel took on the library's
+ * stream, measured with HIP events around the launch; and the number of launches it made.         */
+int rt_last_kernel_ms(float* ms, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAY_AMD_H */

@@ -1,0 +1,125 @@
+"""ctypes access to the CPU oracle (oracle/librt_oracle.so). Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ray_amd.capi import RtCamera, RtScene, SceneArrays
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "librt_oracle.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+f4p, f8p, i4p, u1p = (C.POINTER(t) for t in (C.c_float, C.c_double, C.c_int32, C.c_uint8))
+
+
+def P(a, ty):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ty))
+
+
+class OrcMatKat(C.Structure):
+    _fields_ = ([("n", C.c_int), ("math_mode", C.c_int),
+                 ("in_d", f4p), ("in_n", f4p), ("in_p", f4p), ("in_ff", u1p), ("prm", f4p), ("ir", f8p),
+                 ("lamb_sd", f4p), ("xz_o", f4p),
+                 ("metal_o", f4p), ("metal_d", f4p), ("metal_att", f4p), ("diel_d", f4p), ("diel_att", f4p),
+                 ("lamb_att", f4p), ("lamb_spdf", f8p), ("cos_val", f8p), ("cos_gen", f4p),
+                 ("sph_gen", f4p), ("sph_val", f8p), ("xz_gen", f4p), ("xz_val", f8p), ("xy_gen", f4p),
+                 ("xy_val", f8p), ("yz_gen", f4p), ("yz_val", f8p), ("mix_gen", f4p), ("mix_val", f8p),
+                 ("refl", f4p), ("refr", f4p), ("refr_eta", f8p)])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(ORACLE_SO):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "librt_oracle.so"], check=True)
+        L = C.CDLL(ORACLE_SO)
+        L.orc_refrng_fill.argtypes = [C.c_uint32, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, f4p]
+        L.orc_counter_fill.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, f4p]
+        L.orc_samplers.argtypes = [C.c_uint32] * 3 + [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double] + [f4p] * 4
+        L.orc_sincos.argtypes = [C.c_int, C.c_int, f8p, f8p, f8p]
+        L.orc_pow5.argtypes = [C.c_int, C.c_int, f8p, f8p]
+        L.orc_vec3.argtypes = [C.c_int] + [f4p] * 7
+        L.orc_camera.argtypes = [f4p, f4p, f4p] + [C.c_double] * 4 + [C.POINTER(RtCamera)]
+        L.orc_camera_rays.argtypes = [C.POINTER(RtCamera)] + [C.c_uint32] * 3 + [C.c_int, f4p, f4p, f4p, f4p]
+        L.orc_shape_hits.argtypes = [C.c_int, i4p, f8p, f4p, f4p, C.c_double, f8p, u1p, f8p, f4p, f4p, u1p, f8p]
+        L.orc_materials_kat.argtypes = [C.POINTER(OrcMatKat)]
+        L.orc_tonemap.argtypes = [C.c_int, f4p, i4p, f4p]
+        L.orc_tonemap_rgb32.argtypes = [C.c_int, C.c_int, f4p, C.c_int, C.POINTER(C.c_uint32)]
+        L.orc_hit_rays.argtypes = [C.POINTER(RtScene), C.c_int64, f4p, f4p, C.c_double, C.c_double, i4p, f8p, f4p, f4p, u1p]
+        L.orc_hit_rays.restype = C.c_int
+        L.orc_primary.argtypes = [C.POINTER(RtScene), C.POINTER(RtCamera), C.c_int, C.c_int, C.c_int, C.c_uint64, i4p, f8p]
+        L.orc_primary.restype = C.c_int
+        L.orc_render.argtypes = ([C.POINTER(RtScene), C.POINTER(RtCamera)] + [C.c_int] * 8 +
+                                 [C.POINTER(C.c_uint32), C.c_uint64, C.c_int, C.c_uint32, C.c_int, f4p,
+                                  C.POINTER(C.c_uint64)])
+        L.orc_render.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def camera_of(scene) -> RtCamera:
+    """camera::resetCam through the oracle (camera.h:32-54)."""
+    c = scene.camera
+    out = RtCamera()
+    a = [np.array(v, dtype=np.float32) for v in (c.lookfrom, c.lookat, c.vup)]
+    lib().orc_camera(P(a[0], C.c_float), P(a[1], C.c_float), P(a[2], C.c_float), c.focus, c.vfov, c.aspect,
+                     c.aperture, C.byref(out))
+    return out
+
+
+def primary(scene, W, H, rng_mode=0, seed=0):
+    sa = SceneArrays(scene.flatten())
+    cam = camera_of(scene)
+    prim = np.empty((H, W), dtype=np.int32)
+    t = np.empty((H, W), dtype=np.float64)
+    rc = lib().orc_primary(sa.ref(), C.byref(cam), W, H, rng_mode, seed, P(prim, C.c_int32), P(t, C.c_double))
+    assert rc == 0
+    return prim, t
+
+
+def render(scene, W, H, spp, depth, rng_mode=1, seeds=(1, 2, 3), seed64=0, math_mode=1, flags=0, n_threads=1,
+           y_begin=0, y_count=None, spp_begin=0, accum=None, cam=None):
+    sa = SceneArrays(scene.flatten())
+    cam = cam or camera_of(scene)
+    if accum is None:
+        accum = np.zeros((H, W, 4), dtype=np.float32)
+    rays = C.c_uint64(0)
+    sd = (C.c_uint32 * 3)(*seeds)
+    rc = lib().orc_render(sa.ref(), C.byref(cam), W, H, y_begin, H if y_count is None else y_count, spp_begin, spp, depth,
+                          rng_mode, sd, seed64, math_mode, flags, n_threads, P(accum, C.c_float), C.byref(rays))
+    assert rc == 0
+    return accum, rays.value
+
+
+def hit_rays(scene, ro, rd, t_min, t_max):
+    sa = SceneArrays(scene.flatten())
+    n = ro.shape[0]
+    ro = np.ascontiguousarray(ro, dtype=np.float32); rd = np.ascontiguousarray(rd, dtype=np.float32)
+    prim = np.empty(n, np.int32); t = np.empty(n, np.float64)
+    p = np.empty((n, 3), np.float32); nrm = np.empty((n, 3), np.float32); ff = np.empty(n, np.uint8)
+    rc = lib().orc_hit_rays(sa.ref(), n, P(ro, C.c_float), P(rd, C.c_float), t_min, t_max, P(prim, C.c_int32),
+                            P(t, C.c_double), P(p, C.c_float), P(nrm, C.c_float), P(ff, C.c_uint8))
+    assert rc == 0
+    return prim, t, p, nrm, ff
+
+
+def bits_equal(a, b):
+    """Bitwise equality of two float arrays (NaN payloads and signed zeros included)."""
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    assert a.dtype == b.dtype and a.shape == b.shape, (a.dtype, b.dtype, a.shape, b.shape)
+    iv = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    return np.array_equal(a.view(iv), b.view(iv))
+
+
+def same_values(a, b):
+    """Equality that treats NaN == NaN (any payload) and -0 == +0."""
+    return np.array_equal(a, b, equal_nan=True)
