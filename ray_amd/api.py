@@ -1,0 +1,167 @@
+"""Python host wrapper over the C ABI (include/ray_amd.h). Thin by design: it allocates device
+buffers, moves numpy arrays across and calls the library; all ray work runs in the HIP kernels.
+Used by tests/, bench.py and __graft_entry__.smoke(). There is no CPU path here."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import capi
+from .capi import RtCamera, SceneArrays
+
+RENDER_ACCUMULATE = 1
+RENDER_NORMALS = 2
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class DeviceBuffer:
+    """Device memory obtained from rt_malloc (freed on close / garbage collection)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p()
+        ctx._check(ctx.lib.rt_malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    def zero(self):
+        self.ctx._check(self.ctx.lib.rt_memset(self.ptr, 0, self.nbytes))
+        return self
+
+    def to_numpy(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.rt_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def from_numpy(self, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        self.ctx._check(self.ctx.lib.rt_memcpy_h2d(self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr and self.ctx.lib is not None:
+            self.ctx.lib.rt_free(self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _dev_ptr(x) -> Optional[int]:
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if hasattr(x, "data_ptr"):       # torch tensor on the GPU
+        return int(x.data_ptr())
+    return int(x)
+
+
+class Context:
+    def __init__(self, device: int = 0, lib_path: str = capi.LIB_PATH):
+        self.lib = capi.load_library(lib_path)
+        self._check(self.lib.rt_init(device))
+        self.device = device
+        self._scene_keep = None
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise RtError(self.lib.rt_last_error().decode())
+
+    def close(self):
+        if self.lib is not None:
+            self.lib.rt_shutdown()
+            self.lib = None
+
+    def device_info(self) -> dict:
+        buf = C.create_string_buffer(256)
+        self._check(self.lib.rt_device_info(buf, 256))
+        name, arch, cus, mhz = buf.value.decode().split("|")
+        return dict(name=name, arch=arch, cus=int(cus), clock_mhz=int(mhz))
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    # ---- scene / camera --------------------------------------------------------------------------
+    def upload_scene(self, scene, set_camera: bool = True):
+        sa = scene if isinstance(scene, SceneArrays) else SceneArrays(scene.flatten())
+        self._check(self.lib.rt_upload_scene(sa.ref()))
+        self._scene_keep = sa
+        if set_camera and hasattr(scene, "camera"):
+            self.set_camera(self.camera_from(scene.camera))
+        return sa
+
+    def camera_from(self, cam) -> RtCamera:
+        out = RtCamera()
+        v = [np.array(a, dtype=np.float32) for a in (cam.lookfrom, cam.lookat, cam.vup)]
+        fp = [a.ctypes.data_as(C.POINTER(C.c_float)) for a in v]
+        self._check(self.lib.rt_camera_from_lookat(fp[0], fp[1], fp[2], cam.focus, cam.vfov, cam.aspect, cam.aperture,
+                                                   C.byref(out)))
+        return out
+
+    def set_camera(self, cam: RtCamera):
+        self._check(self.lib.rt_set_camera(C.byref(cam)))
+
+    # ---- hot path --------------------------------------------------------------------------------
+    def primary_hits(self, W: int, H: int, seed: int = 0):
+        dp, dt = self.alloc(W * H * 4), self.alloc(W * H * 8)
+        self._check(self.lib.rt_primary_hits(W, H, seed, dp.ptr, dt.ptr))
+        prim, t = dp.to_numpy(np.int32, (H, W)), dt.to_numpy(np.float64, (H, W))
+        dp.free(); dt.free()
+        return prim, t
+
+    def hit_rays(self, ro: np.ndarray, rd: np.ndarray, t_min: float, t_max: float):
+        ro = np.ascontiguousarray(ro, dtype=np.float32); rd = np.ascontiguousarray(rd, dtype=np.float32)
+        n = ro.shape[0]
+        d_ro, d_rd = self.alloc(max(ro.nbytes, 4)).from_numpy(ro), self.alloc(max(rd.nbytes, 4)).from_numpy(rd)
+        d_prim, d_t = self.alloc(max(n * 4, 4)), self.alloc(max(n * 8, 8))
+        d_p, d_n, d_ff = self.alloc(max(n * 12, 4)), self.alloc(max(n * 12, 4)), self.alloc(max(n, 1))
+        self._check(self.lib.rt_hit_rays(n, d_ro.ptr, d_rd.ptr, t_min, t_max, d_prim.ptr, d_t.ptr, d_p.ptr, d_n.ptr, d_ff.ptr))
+        out = (d_prim.to_numpy(np.int32, (n,)), d_t.to_numpy(np.float64, (n,)), d_p.to_numpy(np.float32, (n, 3)),
+               d_n.to_numpy(np.float32, (n, 3)), d_ff.to_numpy(np.uint8, (n,)))
+        for b in (d_ro, d_rd, d_prim, d_t, d_p, d_n, d_ff):
+            b.free()
+        return out
+
+    def render_into(self, W, H, accum, spp, depth, seed=0, flags=0, y_begin=0, y_count=None, spp_begin=0, rays=None):
+        """rt_render into a caller-owned device accumulator ([H][W][4] float32: DeviceBuffer, torch
+        tensor or raw pointer). `rays`: optional device uint64 counter."""
+        self._check(self.lib.rt_render(W, H, y_begin, H if y_count is None else y_count, spp_begin, spp, depth, seed, flags,
+                                       _dev_ptr(accum), _dev_ptr(rays)))
+
+    def render(self, W, H, spp, depth, seed=0, flags=0, y_begin=0, y_count=None, spp_begin=0):
+        """Convenience: render into a fresh zeroed accumulator and return (accum[H,W,4], n_rays)."""
+        acc = self.alloc(W * H * 16).zero()
+        rays = self.alloc(8).zero()
+        self.render_into(W, H, acc, spp, depth, seed, flags, y_begin, y_count, spp_begin, rays)
+        out = acc.to_numpy(np.float32, (H, W, 4))
+        n = int(rays.to_numpy(np.uint64, (1,))[0])
+        acc.free(); rays.free()
+        return out, n
+
+    def tonemap(self, W, H, accum, n_samples: int = 0) -> np.ndarray:
+        own = None
+        if isinstance(accum, np.ndarray):
+            own = self.alloc(accum.nbytes).from_numpy(accum.astype(np.float32))
+            accum = own
+        img = self.alloc(W * H * 4)
+        self._check(self.lib.rt_tonemap(W, H, _dev_ptr(accum), n_samples, img.ptr))
+        out = img.to_numpy(np.uint32, (H, W))
+        img.free()
+        if own is not None:
+            own.free()
+        return out
+
+    def last_kernel_ms(self):
+        ms, n = C.c_float(0), C.c_int(0)
+        self.lib.rt_last_kernel_ms(C.byref(ms), C.byref(n))
+        return ms.value, n.value

@@ -1,0 +1,171 @@
+// Device-side arithmetic of the ray path for gfx950. Everything here is compiled with
+// -ffp-contract=off: the reference's arithmetic (g++ on x86-64) is FP32
+// QVector3D operators with every multiply and add rounded separately, and FP64 wherever the
+// reference calls an unqualified <cmath> function. IEEE +,-,*,/ and sqrt are correctly rounded on
+// gfx950 in both precisions, so the same sequence of operations gives the same bits as the CPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT_DEV __host__ __device__ __forceinline__
+
+namespace rt {
+
+constexpr double kPi = 3.1415926535897932385;   // reference calc.h:31
+constexpr double kInf = __builtin_huge_val();   // reference calc.h:30
+
+// ---- QVector3D arithmetic (Qt5Gui qvector3d.h:184-284; out-of-line length/normalized/dot/cross as
+// restated in SURVEY.md 8c) ---------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+};
+RT_DEV V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV V3 operator*(float f, V3 v) { return v3(v.x * f, v.y * f, v.z * f); }
+RT_DEV V3 operator*(V3 v, float f) { return v3(v.x * f, v.y * f, v.z * f); }
+RT_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV V3 operator-(V3 v) { return v3(-v.x, -v.y, -v.z); }
+RT_DEV V3 operator/(V3 v, float d) { return v3(v.x / d, v.y / d, v.z / d); }
+RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RT_DEV float length_squared(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
+RT_DEV double len2_f64(V3 v) { return double(v.x) * double(v.x) + double(v.y) * double(v.y) + double(v.z) * double(v.z); }
+RT_DEV float length(V3 v) { return float(__builtin_sqrt(len2_f64(v))); }
+RT_DEV V3 normalized(V3 v) {
+    double len = len2_f64(v);
+    if (__builtin_fabs(len - 1.0) <= 0.000000000001) return v;
+    if (!(__builtin_fabs(len) <= 0.000000000001)) {
+        double s = __builtin_sqrt(len);
+        return v3(float(double(v.x) / s), float(double(v.y) / s), float(double(v.z) / s));
+    }
+    return v3(0.0f, 0.0f, 0.0f);
+}
+
+// ---- portable transcendentals: fdlibm k_sin/k_cos + two-term pi/2 reduction for
+// 0 <= x <= 2*pi, IEEE double +,-,* only; bit-identical to the CPU restatement the parity tests use.
+namespace pm {
+constexpr double invpio2 = 6.36619772367581382433e-01;
+constexpr double pio2_1 = 1.57079632673412561417e+00;
+constexpr double pio2_1t = 6.07710050650619224932e-11;
+constexpr double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+constexpr double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+}  // namespace pm
+RT_DEV void sincos_portable(double x, double* s, double* c) {
+    using namespace pm;
+    int k = int(x * invpio2 + 0.5);
+    double fn = double(k);
+    double r = x - fn * pio2_1;
+    double w = fn * pio2_1t;
+    double y0 = r - w;
+    double y1 = (r - y0) - w;
+    double z = y0 * y0, zz = z * z;
+    // k_sin
+    double rs = S2 + z * (S3 + z * S4) + z * zz * (S5 + z * S6);
+    double v = z * y0;
+    double sn = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    // k_cos
+    double rc = z * (C1 + z * (C2 + z * C3)) + (zz * zz) * (C4 + z * (C5 + z * C6));
+    double hz = 0.5 * z;
+    double wc = 1.0 - hz;
+    double cs = wc + (((1.0 - wc) - hz) + (z * rc - y0 * y1));
+    switch (k & 3) {
+    case 0: *s = sn; *c = cs; break;
+    case 1: *s = cs; *c = -sn; break;
+    case 2: *s = -sn; *c = -cs; break;
+    default: *s = -cs; *c = sn; break;
+    }
+}
+RT_DEV double pow5_portable(double x) { double x2 = x * x; double x4 = x2 * x2; return x4 * x; }
+
+// ---- counter RNG (DESIGN.md "RNG contract"): PCG-RXS-M-XS-32 stream keyed by (seed, pixel, sample);
+// the reference's three minstd_rand0 engines (calc.h:103-108) all map onto it. --------------------
+RT_DEV uint32_t pcg_hash(uint32_t v) {
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
+    return (word >> 22) ^ word;
+}
+struct Rng {
+    uint32_t state;
+    RT_DEV void key(uint64_t seed, uint32_t pixel, uint32_t sample) {
+        uint32_t lo = uint32_t(seed), hi = uint32_t(seed >> 32);
+        state = pcg_hash(pixel + pcg_hash(sample + pcg_hash(lo ^ pcg_hash(hi))));
+    }
+    RT_DEV float canon() {
+        state = state * 747796405u + 2891336453u;
+        uint32_t word = ((state >> ((state >> 28) + 4u)) ^ state) * 277803737u;
+        uint32_t bits = (word >> 22) ^ word;
+        return float(bits >> 8) * 5.9604644775390625e-08f;
+    }
+    // uniform_real_distribution<float>(a, b): canon * (b - a) + a   (reference calc.cpp:12-36)
+    RT_DEV float range(float a, float b) { return canon() * (b - a) + a; }
+    RT_DEV float u01() { return canon() * (1.0f - 0.0f) + 0.0f; }
+    RT_DEV float u11() { return canon() * (1.0f - -1.0f) + -1.0f; }
+};
+
+// reference calc.cpp:54-62 (randomVec11 is a brace-init list: x, y, z drawn in that order)
+RT_DEV V3 random_in_unit_sphere(Rng& g) {
+    V3 p = v3(-1.0f, -1.0f, -1.0f);
+    while (length_squared(p) >= 1.0f) {
+        float x = g.u11(); float y = g.u11(); float z = g.u11();
+        p = v3(x, y, z);
+    }
+    return p;
+}
+// reference calc.cpp:64-72; the reference binary draws y before x (oracle/rt_oracle.cpp, pinned)
+RT_DEV V3 random_in_unit_disk(Rng& g) {
+    for (;;) {
+        float y = g.u11();
+        float x = g.u11();
+        V3 p = v3(x, y, 0.0f);
+        if (!(length_squared(p) >= 1.0f)) return p;
+    }
+}
+// reference calc.h:62-73
+RT_DEV V3 random_cosine_direction(Rng& g) {
+    float r1 = g.u01();
+    float r2 = g.u01();
+    double z = __builtin_sqrt(double(1 - r2));
+    double phi = 2 * kPi * r1;
+    double sn, cs;
+    sincos_portable(phi, &sn, &cs);
+    double sr2 = __builtin_sqrt(double(r2));
+    return v3(float(cs * sr2), float(sn * sr2), float(z));
+}
+// reference calc.h:75-86
+RT_DEV V3 random_to_sphere(Rng& g, double radius, double distance_squared) {
+    float r1 = g.u01();
+    float r2 = g.u01();
+    double z = 1 + r2 * (__builtin_sqrt(1 - radius * radius / distance_squared) - 1);
+    double phi = 2 * kPi * r1;
+    double sn, cs;
+    sincos_portable(phi, &sn, &cs);
+    double sq = __builtin_sqrt(1 - z * z);
+    return v3(float(cs * sq), float(sn * sq), float(z));
+}
+// reference calc.cpp:163-174
+RT_DEV V3 reflect(V3 v, V3 n) { return v - 2 * dot(v, n) * n; }
+RT_DEV V3 refract(V3 uv, V3 n, double etai_over_etat) {
+    double cos_theta = __builtin_fmin(double(dot(-uv, n)), 1.0);
+    V3 r_out_perp = float(etai_over_etat) * (uv + float(cos_theta) * n);
+    V3 r_out_parallel = float(-__builtin_sqrt(__builtin_fabs(1.0 - length_squared(r_out_perp)))) * n;
+    return r_out_perp + r_out_parallel;
+}
+
+// reference hitPosition.h:112-139
+struct Onb {
+    V3 u, v, w;
+    RT_DEV void build_from_w(V3 n) {
+        w = normalized(n);
+        V3 a = (__builtin_fabs(double(w.x)) > 0.9) ? v3(0, 1, 0) : v3(1, 0, 0);
+        v = normalized(cross(w, a));
+        u = cross(w, v);
+    }
+    RT_DEV V3 local(V3 a) const { return a.x * u + a.y * v + a.z * w; }
+};
+
+}  // namespace rt
