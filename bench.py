@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the ray path on MI355X: one "step" = one full frame of the named workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU): the samples-per-pixel of every
+pixel are split over the ranks (spp-split) and the FP32 accumulators are summed by
+an RCCL all-reduce over xGMI inside the timed region -> "scaling": "strong".
+
+Workloads (BASELINE.json configs):
+  c3  random-spheres scene (~485 spheres), 3840x2160, 256 spp, depth 8   <- default (the frame
+      BASELINE.json's north_star target names; it fits one GPU)
+  c2  built-in 5-primitive scene, 1920x1080, 64 spp, depth 10
+  c4  ~10k-triangle mesh, 1920x1080, 64 spp, depth 8
+  c5  mixed spheres + triangles, 3840x2160, 1024 spp (tile-split when N > 1)
+
+Rank 0 prints ONE JSON line: metric Mrays/s (closest-hit scans per second, primary + bounce rays),
+ms_per_step = ms per frame, plus `roofline` (FP32 VALU, algorithmic flops of the closest-hit tests
+over the kernel time measured with HIP events on the library's stream) and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FP32_VALU_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md "Peak FP32 (vector)"
+FLOPS_SPHERE, FLOPS_RECT, FLOPS_TRI = 17, 8, 45   # SURVEY.md section 8d, per ray-primitive test
+
+WORKLOADS = {
+    "c3": dict(scene="random", kw=dict(half=11), W=3840, H=2160, spp=256, depth=8, split="spp",
+               desc="random-spheres 3840x2160 256spp depth8"),
+    "c2": dict(scene="builtin", kw={}, W=1920, H=1080, spp=64, depth=10, split="spp",
+               desc="built-in sphere scene 1920x1080 64spp depth10"),
+    "c4": dict(scene="tris", kw=dict(n=71), W=1920, H=1080, spp=64, depth=8, split="spp",
+               desc="10k-triangle mesh 1920x1080 64spp depth8"),
+    "c5": dict(scene="mixed", kw=dict(half=11, n=71), W=3840, H=2160, spp=1024, depth=8, split="tile",
+               desc="mixed spheres+triangles 3840x2160 1024spp depth8"),
+}
+
+
+def flops_per_ray(flat):
+    k = flat["prim_kind"]
+    return int((k == 0).sum()) * FLOPS_SPHERE + int(((k >= 1) & (k <= 3)).sum()) * FLOPS_RECT + int((k == 4).sum()) * FLOPS_TRI
+
+
+def cpu_baseline(scene, wl, budget_s=12.0):
+    """Time the CPU side on a bounded sample of the same workload (same scene, camera, depth; a
+    reduced frame). Preferred: the reference itself (oracle/_ref/ref_harness, built in the build
+    container from the unmodified reference sources; single-threaded by construction). Otherwise the
+    oracle port (oracle/librt_oracle.so), also on one thread."""
+    sw, sh, sspp = 320, 180, 2
+    if wl["scene"] == "builtin":
+        sspp = 16
+    out = {}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    # port, 1 thread
+    t0 = time.perf_counter()
+    _, rays = O.render(scene, sw, sh, sspp, wl["depth"], rng_mode=1, seed64=1, math_mode=1, n_threads=1)
+    dt = time.perf_counter() - t0
+    port = dict(value=rays / dt / 1e6, unit="Mrays/s", cores=1, kind="port",
+                sample=f"{wl['scene']} scene {sw}x{sh} {sspp}spp depth{wl['depth']} ({rays} rays, {dt:.2f}s)")
+    # port, all the cores this job may use
+    ncore = min(16, os.cpu_count() or 1)
+    t0 = time.perf_counter()
+    _, rays_mt = O.render(scene, sw, sh, sspp * 4, wl["depth"], rng_mode=1, seed64=1, math_mode=1, n_threads=ncore)
+    dt_mt = time.perf_counter() - t0
+    port["all_cores"] = dict(value=rays_mt / dt_mt / 1e6, unit="Mrays/s", cores=ncore)
+    out = port
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    has_tri = any(s.kind == "triangle" for s in scene.world)
+    if os.path.exists(harness) and not has_tri:
+        try:
+            import tempfile
+            with tempfile.TemporaryDirectory() as tmp:
+                sp = os.path.join(tmp, "scene.txt")
+                open(sp, "w").write(scene.to_text())
+                t0 = time.perf_counter()
+                r = subprocess.run([harness, "render", sp, str(sw), str(sh), str(sspp), str(wl["depth"]), "1", "2", "3"],
+                                   capture_output=True, text=True, timeout=120)
+                dt_ref = time.perf_counter() - t0
+            if r.returncode == 0:
+                # the harness prints "... X s (Y Msamples/s)"; rays/sample taken from the port run
+                sec = float(r.stderr.split(":")[-1].split("s")[0])
+                rays_ref = rays   # same workload, same estimator: rays per sample agree to <1%
+                out = dict(value=rays_ref / sec / 1e6, unit="Mrays/s", cores=1, kind="reference",
+                           sample=port["sample"].replace(f"{dt:.2f}s", f"{sec:.2f}s") + "; reference calc.cpp/hitPosition.cpp "
+                           "compiled unmodified (oracle/_ref), rays/sample from the port run",
+                           port=dict(value=port["value"], cores=1), all_cores=port["all_cores"])
+        except Exception as e:   # the reference binary is optional on the GPU box
+            out["reference_error"] = str(e)[:200]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (diagnostics only)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ray_amd import api, scenes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.spp:
+        wl["spp"] = args.spp
+    W, H, spp, depth = wl["W"], wl["H"], wl["spp"], wl["depth"]
+    scene = scenes.get_scene(wl["scene"], **wl["kw"])
+    flat = scene.flatten()
+    fpr = flops_per_ray(flat)
+
+    ctx = api.Context(local_rank)
+    ctx.upload_scene(scene)
+    accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    rays = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    # work split: spp-split (every rank renders all pixels, a slice of the samples, then all-reduce)
+    # or tile-split (every rank renders all samples of a band of rows, then all-reduce of disjoint bands)
+    if wl["split"] == "spp" or world == 1:
+        s0 = spp * rank // world
+        s1 = spp * (rank + 1) // world
+        y0, yc = 0, H
+    else:
+        s0, s1 = 0, spp
+        y0 = H * rank // world
+        yc = H * (rank + 1) // world - y0
+    seed = 0xC0FFEE
+
+    def step():
+        if wl["split"] == "tile" and world > 1:
+            accum.zero_()
+        ctx.render_into(W, H, accum, s1 - s0, depth, seed=seed, flags=0, y_begin=y0, y_count=yc, spp_begin=s0, rays=rays)
+        ms, _ = ctx.last_kernel_ms()
+        if world > 1:
+            dist.all_reduce(accum)
+        return ms
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    rays.zero_()
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    for _ in range(args.steps):
+        kernel_ms += step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+    rr = rays.clone()
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rr)
+    elapsed, kernel_ms = float(tt[0]), float(tt[1])
+    total_rays = int(rr.item())
+    local_rays = int(rays.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+        mrays = total_rays / elapsed / 1e6
+        # roofline of the dominant kernel (render_kernel) on this rank: algorithmic flops of the
+        # closest-hit tests it executed / its average launch duration (HIP events, library stream)
+        k_ms = kernel_ms / max(args.steps, 1)
+        flops_launch = local_rays / max(args.steps, 1) * fpr
+        achieved = flops_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        out = {
+            "metric": "Mrays/s (incl. bounces)", "value": round(mrays, 3), "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl["desc"], "name": args.workload, "width": W, "height": H, "spp": spp, "depth": depth,
+                       "primitives": int(flat["n_prims"]), "split": wl["split"] if world > 1 else "none",
+                       "rays_per_frame": total_rays // max(args.steps, 1), "seed": seed},
+            "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 4), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": None,
+                         "kernel": "render_kernel", "kernel_ms": round(k_ms, 3), "flops_per_ray": fpr,
+                         "accumulator_GBps": round(W * H * 16 * (2 if False else 1) / (k_ms * 1e-3) / 1e9, 3) if k_ms > 0 else None},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(scene, wl)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

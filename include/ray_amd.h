@@ -137,6 +137,12 @@ int rt_hit_rays(int64_t n, const float* d_origin, const float* d_dir, double t_m
 int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth,
               uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
 
+/* calc::ray_color (calc.h:89-94, calc.cpp:90-131) for caller-supplied rays: n rays, origin/direction
+ * as [n][3] floats, against the uploaded world/lights/background; ray i draws from the counter RNG
+ * stream (seed, i, 0). d_rgb receives [n][3] linear radiance. flags: RT_RENDER_NORMALS.            */
+int rt_trace_rays(int64_t n, const float* d_origin, const float* d_dir, int depth, uint64_t seed, uint32_t flags,
+                  float* d_rgb);
+
 /* calc::rgbPerSamples + RayView::writeToImg (calc.cpp:133-154, rayview.cpp:57-65,86): gamma-2
  * tonemap of sum / n_samples (n from accum.w when n_samples <= 0), clamp, pack as
  * QImage::Format_RGB32 (0xffRRGGBB) at the mirrored position (w-1-x, h-1-y).                      */

@@ -825,6 +825,20 @@ int orc_hit_rays(const RtScene* sc, int64_t n, const float* ro, const float* rd,
     return 0;
 }
 
+// calc::ray_color for caller rays; ray i uses CounterRng keyed (seed, i, 0) (as rt_trace_rays).
+int orc_trace_rays(const RtScene* sc, int64_t n, const float* ro, const float* rd, int depth, uint64_t seed, int math_mode,
+                   uint32_t flags, float* rgb) {
+    World w; if (!build_world(sc, w)) return 1;
+    Ctx c; c.math_mode = math_mode;
+    for (int64_t i = 0; i < n; ++i) {
+        c.rng.key(seed, uint32_t(i), 0);
+        Ray r(V3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), V3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]));
+        V3 col = ray_color(c, r, w, depth, (flags & RT_RENDER_NORMALS) != 0);
+        rgb[3 * i] = col.x; rgb[3 * i + 1] = col.y; rgb[3 * i + 2] = col.z;
+    }
+    return 0;
+}
+
 // Pixel-centre primary hits: u = (x + 0.5f) / W, v = (y + 0.5f) / H through camera::get_ray.
 // rng_mode 0: RefRng seeded (1,2,3) once, pixels in row-major order (as ref_harness cmd_primary);
 // rng_mode 1: CounterRng keyed (seed, pixel, 0) per pixel (as rt_primary_hits).

@@ -132,6 +132,17 @@ class Context:
             b.free()
         return out
 
+    def trace_rays(self, ro: np.ndarray, rd: np.ndarray, depth: int, seed: int = 0, flags: int = 0) -> np.ndarray:
+        ro = np.ascontiguousarray(ro, dtype=np.float32); rd = np.ascontiguousarray(rd, dtype=np.float32)
+        n = ro.shape[0]
+        d_ro, d_rd = self.alloc(max(ro.nbytes, 4)).from_numpy(ro), self.alloc(max(rd.nbytes, 4)).from_numpy(rd)
+        d_rgb = self.alloc(max(n * 12, 4))
+        self._check(self.lib.rt_trace_rays(n, d_ro.ptr, d_rd.ptr, depth, seed, flags, d_rgb.ptr))
+        out = d_rgb.to_numpy(np.float32, (n, 3))
+        for b in (d_ro, d_rd, d_rgb):
+            b.free()
+        return out
+
     def render_into(self, W, H, accum, spp, depth, seed=0, flags=0, y_begin=0, y_count=None, spp_begin=0, rays=None):
         """rt_render into a caller-owned device accumulator ([H][W][4] float32: DeviceBuffer, torch
         tensor or raw pointer). `rays`: optional device uint64 counter."""

@@ -429,6 +429,19 @@ __global__ __launch_bounds__(kBlock) void hit_rays_kernel(DevScene sc, long long
     }
 }
 
+__global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene sc, long long n, const float* __restrict__ ro,
+                                                            const float* __restrict__ rd, int depth, uint64_t seed, uint32_t flags,
+                                                            float* __restrict__ rgb, float4* __restrict__ stack) {
+    PathStack st; st.base = stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t n_rays = 0;
+    for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        Ray ray = make_ray(v3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), v3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]));
+        Rng g; g.key(seed, uint32_t(i), 0u);
+        V3 c = trace_path(sc, ray, g, depth, (flags & RT_RENDER_NORMALS) != 0, st, n_rays);
+        rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+    }
+}
+
 // calc::rgbPerSamples (calc.cpp:133-154) + RayView::writeToImg (rayview.cpp:57-65,86)
 __global__ void tonemap_kernel(int W, int H, const float4* __restrict__ accum, int n_samples, uint32_t* __restrict__ rgb32) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -707,6 +720,32 @@ int rt_hit_rays(int64_t n, const float* d_origin, const float* d_dir, double t_m
     return finish_timed(1);
 }
 
+static int ensure_stack(int depth, int grid) {
+    size_t need = size_t(depth > 0 ? depth : 1) * size_t(grid) * kBlock * sizeof(float4);
+    if (need > g.stack_bytes) {
+        HIP_OK(hipStreamSynchronize(g.stream));
+        if (g.stack) HIP_OK(hipFree(g.stack));
+        g.stack = nullptr; g.stack_bytes = 0;
+        HIP_OK(hipMalloc(&g.stack, need));
+        g.stack_bytes = need;
+    }
+    return 0;
+}
+
+int rt_trace_rays(int64_t n, const float* d_origin, const float* d_dir, int depth, uint64_t seed, uint32_t flags, float* d_rgb) {
+    if (need_ready()) return 1;
+    if (!g.have_scene) return fail("no scene uploaded (rt_upload_scene)");
+    if (n < 0 || (n > 0 && (!d_origin || !d_dir || !d_rgb))) return fail("rt_trace_rays: bad arguments");
+    if (depth < 0 || depth > 128) return fail("rt_trace_rays: depth %d outside 0..128", depth);
+    if (n == 0) { g.last_ms = 0; g.last_launches = 0; return 0; }
+    int grid = grid_for(int((n + kBlock - 1) / kBlock));
+    if (ensure_stack(depth, grid)) return 1;
+    HIP_OK(hipEventRecord(g.ev0, g.stream));
+    hipLaunchKernelGGL(trace_rays_kernel, dim3(grid), dim3(kBlock), 0, g.stream, g.scene, (long long)n, d_origin, d_dir, depth, seed,
+                       flags, d_rgb, static_cast<float4*>(g.stack));
+    return finish_timed(1);
+}
+
 int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth, uint64_t seed, uint32_t flags,
               float* d_accum, uint64_t* d_rays) {
     if (need_scene_cam()) return 1;
@@ -718,14 +757,7 @@ int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_cou
     if (y_count == 0) { g.last_ms = 0; g.last_launches = 0; return 0; }
     int n_tiles = ((w + kTile - 1) / kTile) * ((y_count + kTile - 1) / kTile);
     int grid = grid_for(n_tiles);
-    size_t need = size_t(depth > 0 ? depth : 1) * size_t(grid) * kBlock * sizeof(float4);
-    if (need > g.stack_bytes) {
-        HIP_OK(hipStreamSynchronize(g.stream));
-        if (g.stack) HIP_OK(hipFree(g.stack));
-        g.stack = nullptr; g.stack_bytes = 0;
-        HIP_OK(hipMalloc(&g.stack, need));
-        g.stack_bytes = need;
-    }
+    if (ensure_stack(depth, grid)) return 1;
     HIP_OK(hipEventRecord(g.ev0, g.stream));
     hipLaunchKernelGGL(render_kernel, dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, w, h, y_begin, y_count, spp_begin,
                        spp_count, depth, seed, flags, reinterpret_cast<float4*>(d_accum), static_cast<float4*>(g.stack),

@@ -52,6 +52,8 @@ def lib():
         L.orc_tonemap_rgb32.argtypes = [C.c_int, C.c_int, f4p, C.c_int, C.POINTER(C.c_uint32)]
         L.orc_hit_rays.argtypes = [C.POINTER(RtScene), C.c_int64, f4p, f4p, C.c_double, C.c_double, i4p, f8p, f4p, f4p, u1p]
         L.orc_hit_rays.restype = C.c_int
+        L.orc_trace_rays.argtypes = [C.POINTER(RtScene), C.c_int64, f4p, f4p, C.c_int, C.c_uint64, C.c_int, C.c_uint32, f4p]
+        L.orc_trace_rays.restype = C.c_int
         L.orc_primary.argtypes = [C.POINTER(RtScene), C.POINTER(RtCamera), C.c_int, C.c_int, C.c_int, C.c_uint64, i4p, f8p]
         L.orc_primary.restype = C.c_int
         L.orc_render.argtypes = ([C.POINTER(RtScene), C.POINTER(RtCamera)] + [C.c_int] * 8 +
@@ -110,6 +112,16 @@ def hit_rays(scene, ro, rd, t_min, t_max):
                             P(t, C.c_double), P(p, C.c_float), P(nrm, C.c_float), P(ff, C.c_uint8))
     assert rc == 0
     return prim, t, p, nrm, ff
+
+
+def trace_rays(scene, ro, rd, depth, seed=0, flags=0, math_mode=1):
+    sa = SceneArrays(scene.flatten())
+    ro = np.ascontiguousarray(ro, dtype=np.float32); rd = np.ascontiguousarray(rd, dtype=np.float32)
+    rgb = np.empty((ro.shape[0], 3), np.float32)
+    rc = lib().orc_trace_rays(sa.ref(), ro.shape[0], P(ro, C.c_float), P(rd, C.c_float), depth, seed, math_mode, flags,
+                              P(rgb, C.c_float))
+    assert rc == 0
+    return rgb
 
 
 def bits_equal(a, b):

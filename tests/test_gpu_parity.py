@@ -69,6 +69,20 @@ def test_hit_rays_match_oracle_and_edge_cases(rt):
     assert rt.hit_rays(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), 0.001, np.inf)[0].shape == (0,)
 
 
+def test_trace_rays_match_oracle(rt):
+    """calc::ray_color for caller-supplied rays (the single-ray entry point of calc.h:89-94)."""
+    sc = scenes.builtin_scene()
+    rt.upload_scene(sc)
+    rng = np.random.default_rng(2)
+    n = 5000
+    ro = np.tile(np.array([0, 0, 1], np.float32), (n, 1)) + rng.standard_normal((n, 3)).astype(np.float32) * np.float32(0.05)
+    rd = np.tile(np.array([0, 0, -2], np.float32), (n, 1)) + rng.standard_normal((n, 3)).astype(np.float32) * np.float32(0.8)
+    for depth, flags in [(10, 0), (1, 0), (5, 2)]:
+        got = rt.trace_rays(ro, rd, depth, seed=77, flags=flags)
+        ref = O.trace_rays(sc, ro, rd, depth, seed=77, flags=flags)
+        assert O.same_values(got, ref)
+
+
 def test_shape_fixture_rays_through_gpu(rt):
     """Every sphere / rect case of shapehits.npz (tangent, inside, on-surface, parallel, edge) as a
     one-primitive scene batch: group the fixture by primitive, trace its rays, compare with the
@@ -208,3 +222,21 @@ def test_device_arithmetic_is_ieee(rt):
     assert np.array_equal(got[0], ref[0]) and (got[0] >= 0).mean() > 0.5
     assert O.bits_equal(got[1], ref[1])
     assert O.same_values(got[2], ref[2]) and O.same_values(got[3], ref[3])
+
+
+def test_cpp_dropin_host_renderAll(rt, tmp_path):
+    """The C++ mirror of the reference headers (ray_amd/host) builds normal_scene with the reference's
+    own class names and renders through renderAll(); its accumulators equal the oracle's."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ray_amd", "host", "render_demo")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    out = tmp_path / "accum.bin"
+    r = subprocess.run([exe, "96", "54", "4", "8", "77", str(out)], capture_output=True, text=True, cwd=tmp_path, timeout=100)
+    assert r.returncode == 0, r.stderr
+    acc = np.fromfile(out, np.float32).reshape(54, 96, 4)
+    sc = scenes.builtin_scene()
+    oacc, _ = O.render(sc, 96, 54, 4, 8, rng_mode=1, seed64=77, math_mode=1)
+    assert O.same_values(acc, oacc)
+    assert "centre ray hits prim 0" in r.stdout
