@@ -79,6 +79,8 @@ typedef struct RtCamera {
 /* flags for rt_render                                                                              */
 #define RT_RENDER_ACCUMULATE 1u /* add to d_accum instead of overwriting it (progressive passes)    */
 #define RT_RENDER_NORMALS 2u    /* drawOnlyColors mode of calc::ray_color (calc.cpp:105-109)        */
+#define RT_RENDER_VERIFY 4u     /* self-check: every closest-hit scan is repeated as the reference's  */
+                                /* list-order loop and compared (slow; see rt_verify_mismatches)      */
 
 /* ---- context ------------------------------------------------------------------------------------ */
 /* Bind this process to HIP device `device` and create the library's stream. Fails (no CPU
@@ -136,6 +138,11 @@ int rt_hit_rays(int64_t n, const float* d_origin, const float* d_dir, double t_m
  * Pixels outside [y_begin, y_begin + y_count) are not touched (image-tile split).                 */
 int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth,
               uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
+
+/* Number of closest-hit scans of the last RT_RENDER_VERIFY render whose fast result (primitive or t
+ * bits) differed from hitFromList's list-order loop (hitPosition.cpp:6-22) run on the same ray. No
+ * counterpart in the reference: it checks the sphere filter of rt_scan.hpp at full frame sizes.     */
+int rt_verify_mismatches(uint64_t* count);
 
 /* calc::ray_color (calc.h:89-94, calc.cpp:90-131) for caller-supplied rays: n rays, origin/direction
  * as [n][3] floats, against the uploaded world/lights/background; ray i draws from the counter RNG

@@ -13,6 +13,7 @@ from .capi import RtCamera, SceneArrays
 
 RENDER_ACCUMULATE = 1
 RENDER_NORMALS = 2
+RENDER_VERIFY = 4
 
 
 class RtError(RuntimeError):
@@ -171,6 +172,11 @@ class Context:
         if own is not None:
             own.free()
         return out
+
+    def verify_mismatches(self) -> int:
+        n = C.c_uint64(0)
+        self._check(self.lib.rt_verify_mismatches(C.byref(n)))
+        return n.value
 
     def last_kernel_ms(self):
         ms, n = C.c_float(0), C.c_int(0)

@@ -6,15 +6,18 @@
 // No CPU fallback: every compute entry point needs rt_init() to have bound a HIP device.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
 #include "../../include/ray_amd.h"
 #include "rt_device.hpp"
+#include "rt_scan.hpp"
 
 using namespace rt;
 
@@ -41,6 +44,7 @@ struct DevScene {
     float light_c[3], light_r;             // sphere light
     double light_rect[5];                  // rect light
     float bg[3];
+    SphereGroups sg;                       // exact / filter partition of the sphere arrays (rt_scan.hpp)
 };
 
 struct DevCamera {
@@ -70,9 +74,7 @@ __device__ __forceinline__ Ray get_ray(const DevCamera& c, Rng& g, float s, floa
 // reject(t) = t < t_min || bt < t || (t == bt && idx < bi). NaN compares false everywhere, exactly
 // as in the reference, so a NaN t is "accepted"; the caller handles that case (see closest_hit).
 // ------------------------------------------------------------------------------------------------
-RT_DEV bool reject_t(double t, double t_min, double bt, int idx, int bi) {
-    return t < t_min || bt < t || (t == bt && idx < bi);
-}
+// reject_t: rt_scan.hpp
 
 // sphere::hit, shapes.h:77-97
 RT_DEV bool sphere_t(const Ray& r, float4 s, double t_min, double bt, int idx, int bi, double* t_out) {
@@ -137,7 +139,7 @@ struct Hit {
 // scan equals "smallest t, ties to the later entry", which is what the grouped scan computes. If any
 // accepted t is NaN the list order matters (a NaN closest_so_far accepts everything after it), so
 // that lane redoes the scan in list order -- rare (a ray component exactly 0 on a plane it lies in).
-__device__ __noinline__ Hit closest_hit_listorder(const DevScene& sc, const Ray& r, double t_min, double t_max) {
+__device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const Ray& r, double t_min, double t_max) {
     Hit h; h.t = t_max; h.prim = -1;
     for (int i = 0; i < sc.n_prims; ++i) {
         int k = sc.prim_kind[i], j = sc.prim_local[i];
@@ -150,29 +152,33 @@ __device__ __noinline__ Hit closest_hit_listorder(const DevScene& sc, const Ray&
     return h;
 }
 
-__device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, double t_min, double t_max) {
+// Fast scan: spheres through rt_scan.hpp (filter + exact), then rects and triangles. Lanes whose ray
+// is outside the fast range (non-finite, huge, zero direction), a scene that is, or a NaN t from a
+// rect, fall back to the list-order scan, which is the reference loop itself.
+__device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, double t_min, double t_max, uint32_t* words) {
     Hit h; h.t = t_max; h.prim = -1;
-    bool saw_nan = false;
-    for (int j = 0; j < sc.n_sph; ++j) {
-        double t;
-        int idx = sc.sph_prim[j];
-        if (sphere_t(r, sc.sph[j], t_min, h.t, idx, h.prim, &t)) {
-            if (t != t) saw_nan = true; else { h.t = t; h.prim = idx; }
+    bool ok = sc.sg.fast_ok && ray_in_fast_range(r.o, r.d, r.dl2) && t_min == t_min && t_max == t_max;
+    if (ok) {
+        HitState hs; hs.bt = t_max; hs.bi = -1; hs.btf = __double2float_ru(t_max);
+        const float tminf = __double2float_rd(t_min);
+        scan_spheres(sc.sg, sc.sph, sc.sph_prim, r.o, r.d, r.dl2, t_min, tminf, hs, words);
+        h.t = hs.bt; h.prim = hs.bi;
+        bool saw_nan = false;
+        for (int j = 0; j < sc.n_rect; ++j) {
+            double t;
+            int idx = sc.rect_prim[j];
+            if (rect_t(r, sc.rect_axis[j], sc.rect + 5 * j, t_min, h.t, idx, h.prim, &t)) {
+                if (t != t) saw_nan = true; else { h.t = t; h.prim = idx; }
+            }
         }
-    }
-    for (int j = 0; j < sc.n_rect; ++j) {
-        double t;
-        int idx = sc.rect_prim[j];
-        if (rect_t(r, sc.rect_axis[j], sc.rect + 5 * j, t_min, h.t, idx, h.prim, &t)) {
-            if (t != t) saw_nan = true; else { h.t = t; h.prim = idx; }
+        for (int j = 0; j < sc.n_tri; ++j) {
+            double t;
+            int idx = sc.tri_prim[j];
+            if (tri_t(r, sc.tri + 12 * j, t_min, h.t, idx, h.prim, &t)) { h.t = t; h.prim = idx; }
         }
+        ok = !saw_nan;
     }
-    for (int j = 0; j < sc.n_tri; ++j) {
-        double t;
-        int idx = sc.tri_prim[j];
-        if (tri_t(r, sc.tri + 12 * j, t_min, h.t, idx, h.prim, &t)) { h.t = t; h.prim = idx; }
-    }
-    if (saw_nan) h = closest_hit_listorder(sc, r, t_min, t_max);
+    if (!ok) h = closest_hit_listorder(sc, r, t_min, t_max);
     return h;
 }
 
@@ -254,7 +260,8 @@ __device__ __forceinline__ V3 light_random(const DevScene& sc, Rng& g, V3 o) {
 //     L_k = attenuation * L_{k+1}                                                      (specular)
 // so each level pushes (w = attenuation [* float(spdf)], pdf) on a per-thread stack in HBM and the
 // radiance is unwound from the terminal value in the reference's own order of operations:
-// bit-identical per-sample colours, not just "within tolerance".
+// bit-identical per-sample colours, not just "within tolerance". A specular level is stored with
+// pdf = -1 (a mixture pdf value is >= 0 or NaN, never -1).
 // ------------------------------------------------------------------------------------------------
 struct PathStack {
     float4* __restrict__ base;   // [depth][stride] entries (w.xyz, pdf)
@@ -262,150 +269,241 @@ struct PathStack {
     RT_DEV void push(int level, V3 w, float pdf) { base[size_t(level) * stride + tid] = make_float4(w.x, w.y, w.z, pdf); }
     RT_DEV float4 get(int level) const { return base[size_t(level) * stride + tid]; }
 };
+constexpr float kSpecularMark = -1.0f;
 
-__device__ __forceinline__ V3 trace_path(const DevScene& sc, Ray ray, Rng& g, int depth, bool normals, PathStack& st,
-                                         uint32_t& n_rays) {
-    int level = 0;
-    uint64_t spec_lo = 0, spec_hi = 0;   // bit k set: level k is a specular bounce (depth <= 128)
-    V3 L = v3(0.0f, 0.0f, 0.0f);
-    for (int depth_left = depth;; --depth_left) {
-        if (depth_left <= 0) { L = v3(0.0f, 0.0f, 0.0f); break; }           // calc.cpp:96-97
-        ++n_rays;
-        Hit h = closest_hit(sc, ray, double(0.001f), kInf);                  // calc.cpp:99
-        if (h.prim < 0) { L = v3(sc.bg[0], sc.bg[1], sc.bg[2]); break; }      // calc.cpp:100-103
-        if (normals) {                                                       // calc.cpp:105-109
-            V3 N = normalized(ray_at(ray, h.t) - v3(0.0f, 0.0f, -1.0f));
-            L = 0.5f * v3(N.x + 1.0f, N.y + 1.0f, N.z + 1.0f);
-            break;
-        }
-        HitRec rec = hit_record(sc, ray, h);
-        int m = sc.prim_mat[h.prim];
-        int mk = sc.mat_kind[m];
-        V3 rgb = v3(sc.mat_rgb[3 * m], sc.mat_rgb[3 * m + 1], sc.mat_rgb[3 * m + 2]);
-        if (mk == RT_MAT_DIFFUSE_LIGHT) { L = rgb; break; }                   // hitPosition.h:301-310, calc.cpp:115-116
-        bool specular;
-        V3 w;
-        float pdf = 1.0f;
-        if (mk == RT_MAT_METAL) {                                            // hitPosition.h:230-239
-            V3 reflected = reflect(normalized(ray.d), rec.normal);
-            float fuzz = sc.mat_fuzz[m];
-            ray = make_ray(rec.p, reflected + fuzz * random_in_unit_sphere(g));
-            specular = true; w = rgb;
-        } else if (mk == RT_MAT_DIELECTRIC) {                                // hitPosition.h:253-287
-            double ir = sc.mat_ir[m];
-            double refraction_ratio = rec.front_face ? (1.0 / ir) : ir;
-            V3 unit_direction = normalized(ray.d);
-            float cos_theta = float(__builtin_fmin(double(dot(-unit_direction, rec.normal)), 1.0));
-            float sin_theta = float(__builtin_sqrt(double(1.0f - cos_theta * cos_theta)));
-            bool cannot_refract = refraction_ratio * double(sin_theta) > 1.0;
-            bool do_reflect = cannot_refract;
-            if (!do_reflect) {
-                float ref_idx = float(refraction_ratio);
-                float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
-                r0 = r0 * r0;
-                float refl = r0 + (1.0f - r0) * float(pow5_portable(double(1.0f - cos_theta)));
-                do_reflect = refl > g.u01();
-            }
-            V3 direction = do_reflect ? reflect(unit_direction, rec.normal)
-                                      : refract(unit_direction, rec.normal, refraction_ratio);
-            ray = make_ray(rec.p, direction);
-            specular = true; w = v3(1.0f, 1.0f, 1.0f);
-        } else {                                                             // lambertian, hitPosition.h:202-216
-            Onb uvw;
-            uvw.build_from_w(rec.normal);                                    // cosine_pdf ctor, hitPosition.h:143
-            V3 dir;
-            if (g.u01() < 0.5f) dir = light_random(sc, g, rec.p);            // mixture_pdf::generate, hitPosition.cpp:67-72
-            else dir = uvw.local(random_cosine_direction(g));
-            Ray scattered = make_ray(rec.p, dir);
-            V3 ndir = normalized(dir);
-            float cosine_s = dot(rec.normal, ndir);                          // lambertian::scattering_pdf
-            double spdf = cosine_s < 0 ? 0.0 : double(cosine_s) / kPi;
-            float cosine_c = dot(ndir, uvw.w);                               // cosine_pdf::value
-            double cval = (cosine_c <= 0) ? 0.0 : double(cosine_c) / kPi;
-            double pval = 0.5 * light_pdf_value(sc, rec.p, dir) + 0.5 * cval;   // mixture_pdf::value
-            ray = scattered;
-            specular = false; w = rgb * float(spdf); pdf = float(pval);
-        }
-        st.push(level, w, pdf);
-        if (specular) { if (level < 64) spec_lo |= 1ull << level; else spec_hi |= 1ull << (level - 64); }
-        ++level;
+// One bounce: the body of ray_color after hitFromList returned `h` for `ray`. Returns true when the
+// path ends here with terminal radiance L (miss, light, normal view); otherwise pushes this level's
+// weight and replaces `ray` by the scattered / specular ray.
+__device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const Hit& h, Rng& g, bool normals, PathStack& st, int level,
+                                             V3& L) {
+    if (h.prim < 0) { L = v3(sc.bg[0], sc.bg[1], sc.bg[2]); return true; }      // calc.cpp:100-103
+    if (normals) {                                                          // calc.cpp:105-109
+        V3 N = normalized(ray_at(ray, h.t) - v3(0.0f, 0.0f, -1.0f));
+        L = 0.5f * v3(N.x + 1.0f, N.y + 1.0f, N.z + 1.0f);
+        return true;
     }
-    while (level > 0) {                                                      // unwind, innermost first
+    HitRec rec = hit_record(sc, ray, h);
+    int m = sc.prim_mat[h.prim];
+    int mk = sc.mat_kind[m];
+    V3 rgb = v3(sc.mat_rgb[3 * m], sc.mat_rgb[3 * m + 1], sc.mat_rgb[3 * m + 2]);
+    if (mk == RT_MAT_DIFFUSE_LIGHT) { L = rgb; return true; }                // hitPosition.h:301-310, calc.cpp:115-116
+    V3 w;
+    float pdf = kSpecularMark;
+    if (mk == RT_MAT_METAL) {                                               // hitPosition.h:230-239
+        V3 reflected = reflect(normalized(ray.d), rec.normal);
+        float fuzz = sc.mat_fuzz[m];
+        ray = make_ray(rec.p, reflected + fuzz * random_in_unit_sphere(g));
+        w = rgb;
+    } else if (mk == RT_MAT_DIELECTRIC) {                                   // hitPosition.h:253-287
+        double ir = sc.mat_ir[m];
+        double refraction_ratio = rec.front_face ? (1.0 / ir) : ir;
+        V3 unit_direction = normalized(ray.d);
+        float cos_theta = float(__builtin_fmin(double(dot(-unit_direction, rec.normal)), 1.0));
+        float sin_theta = float(__builtin_sqrt(double(1.0f - cos_theta * cos_theta)));
+        bool cannot_refract = refraction_ratio * double(sin_theta) > 1.0;
+        bool do_reflect = cannot_refract;
+        if (!do_reflect) {
+            float ref_idx = float(refraction_ratio);
+            float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+            r0 = r0 * r0;
+            float refl = r0 + (1.0f - r0) * float(pow5_portable(double(1.0f - cos_theta)));
+            do_reflect = refl > g.u01();
+        }
+        V3 direction = do_reflect ? reflect(unit_direction, rec.normal)
+                                  : refract(unit_direction, rec.normal, refraction_ratio);
+        ray = make_ray(rec.p, direction);
+        w = v3(1.0f, 1.0f, 1.0f);
+    } else {                                                                // lambertian, hitPosition.h:202-216
+        Onb uvw;
+        uvw.build_from_w(rec.normal);                                       // cosine_pdf ctor, hitPosition.h:143
+        V3 dir;
+        if (g.u01() < 0.5f) dir = light_random(sc, g, rec.p);               // mixture_pdf::generate, hitPosition.cpp:67-72
+        else dir = uvw.local(random_cosine_direction(g));
+        V3 ndir = normalized(dir);
+        float cosine_s = dot(rec.normal, ndir);                             // lambertian::scattering_pdf
+        double spdf = cosine_s < 0 ? 0.0 : double(cosine_s) / kPi;
+        float cosine_c = dot(ndir, uvw.w);                                  // cosine_pdf::value
+        double cval = (cosine_c <= 0) ? 0.0 : double(cosine_c) / kPi;
+        double pval = 0.5 * light_pdf_value(sc, rec.p, dir) + 0.5 * cval;   // mixture_pdf::value
+        ray = make_ray(rec.p, dir);
+        w = rgb * float(spdf); pdf = float(pval);
+        if (pdf == kSpecularMark) pdf = -pdf;   // unreachable (pval >= 0 or NaN); keeps the mark unambiguous
+    }
+    st.push(level, w, pdf);
+    return false;
+}
+
+// Unwind `level` pushed bounces from the terminal radiance L, innermost first.
+__device__ __forceinline__ V3 unwind_path(const PathStack& st, int level, V3 L) {
+    while (level > 0) {
         --level;
         float4 e = st.get(level);
-        bool specular = level < 64 ? ((spec_lo >> level) & 1) : ((spec_hi >> (level - 64)) & 1);
         V3 w = v3(e.x, e.y, e.z);
-        if (specular) L = w * L;                                              // calc.cpp:119-120
-        else L = v3(0.0f, 0.0f, 0.0f) + w * L / e.w;                          // calc.cpp:129-130 (emitted == 0)
+        if (e.w == kSpecularMark) L = w * L;                                 // calc.cpp:119-120
+        else L = v3(0.0f, 0.0f, 0.0f) + w * L / e.w;                         // calc.cpp:129-130 (emitted == 0)
     }
     return L;
+}
+
+// ray_color for one ray, simple per-thread loop (rt_trace_rays).
+__device__ __forceinline__ V3 trace_path(const DevScene& sc, Ray ray, Rng& g, int depth, bool normals, PathStack& st, uint32_t* words) {
+    int level = 0;
+    V3 L = v3(0.0f, 0.0f, 0.0f);
+    for (int depth_left = depth; depth_left > 0; --depth_left) {            // depth_left <= 0: black, calc.cpp:96-97
+        Hit h = closest_hit(sc, ray, double(0.001f), kInf, words);           // calc.cpp:99
+        if (shade_bounce(sc, ray, h, g, normals, st, level, L)) break;
+        ++level;
+        L = v3(0.0f, 0.0f, 0.0f);
+    }
+    return unwind_path(st, level, L);
 }
 
 // ================================================================================================
 // Kernels
 // ================================================================================================
-constexpr int kBlock = 256;   // 4 waves; each wave covers an 8x8 pixel tile of a 16x16 block tile
-constexpr int kTile = 16;
+constexpr int kBlock = kScanBlock;   // 4 waves
+constexpr int kTile = 8;             // work unit handed to a wave: one 8x8 pixel tile
 
-__device__ __forceinline__ void tile_xy(int tile, int tiles_x, int y_begin, int& x, int& y) {
-    int t = threadIdx.x;
-    int wave = t >> 6, lane = t & 63;
-    int lx = (lane & 7) + 8 * (wave & 1);
-    int ly = (lane >> 3) + 8 * (wave >> 1);
-    x = (tile % tiles_x) * kTile + lx;
-    y = y_begin + (tile / tiles_x) * kTile + ly;
+struct RenderArgs {
+    int W, H, y_begin, y_count, spp_begin, spp_count, depth;
+    uint64_t seed;
+    uint32_t flags;
+    float4* __restrict__ accum;
+    float4* __restrict__ stack;
+    unsigned long long* __restrict__ rays_out;
+    unsigned int* __restrict__ work_counter;       // next tile to hand out, zeroed before the launch
+    unsigned long long* __restrict__ mismatches;   // VERIFY builds: scans whose fast result differs from the list-order scan
+};
+
+// Persistent waves with path regeneration. Every lane owns one pixel at a time and walks its samples
+// in order (the reference sums a pixel's samples in order, rayview.cpp:79-84); each trip of the main
+// loop does exactly ONE closest-hit scan for every lane that has a pixel, whatever bounce its path is
+// at, so the 64 lanes of a wave stay in the scan together instead of waiting for the longest path.
+// A lane whose pixel is finished takes the next pixel of the wave's tile queue; an empty queue is
+// refilled with one 8x8 tile from a global counter (one atomic per wave and tile).
+template <bool VERIFY>
+__global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra) {
+    __shared__ uint32_t s_words[kMaskWords * kBlock];
+    uint32_t* words = s_words + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int tiles_x = (ra.W + kTile - 1) / kTile, tiles_y = (ra.y_count + kTile - 1) / kTile;
+    const int total = tiles_x * tiles_y * 64;
+    PathStack st; st.base = ra.stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
+    const bool normals = (ra.flags & RT_RENDER_NORMALS) != 0;
+    const int spp_end = ra.spp_begin + ra.spp_count;
+
+    bool have = false, path = false;
+    int x = 0, y = 0, s = 0, level = 0, depth_left = 0;
+    uint32_t pix = 0, n_rays = 0;
+    V3 sum = v3(0.0f, 0.0f, 0.0f);
+    Ray ray = make_ray(v3(0, 0, 0), v3(0, 0, 0));
+    Rng g; g.state = 0;
+    int q_cur = 0, q_end = 0;      // wave-uniform: the wave's queue of work indices
+    bool exhausted = false;        // wave-uniform: the global counter has run past the last tile
+
+    for (;;) {
+        // ---- hand pixels to idle lanes ------------------------------------------------------------
+        for (;;) {
+            const unsigned long long need = __ballot(!have);
+            if (need == 0ull) break;
+            if (q_cur >= q_end) {
+                if (exhausted) break;
+                int base = 0;
+                if (lane == 0) base = int(atomicAdd(ra.work_counter, 64u));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= total) { exhausted = true; break; }
+                q_cur = base; q_end = base + 64;
+            }
+            const int rank = __popcll(need & ((1ull << lane) - 1ull));
+            const int avail = q_end - q_cur;
+            if (!have && rank < avail) {
+                const int idx = q_cur + rank;
+                const int tile = idx >> 6, in = idx & 63;
+                x = (tile % tiles_x) * kTile + (in & 7);
+                y = ra.y_begin + (tile / tiles_x) * kTile + (in >> 3);
+                if (x < ra.W && y < ra.y_begin + ra.y_count) {
+                    have = true; path = false;
+                    pix = uint32_t(y) * uint32_t(ra.W) + uint32_t(x);
+                    s = ra.spp_begin;
+                    sum = v3(0.0f, 0.0f, 0.0f);
+                }
+            }
+            const int want = __popcll(need);
+            q_cur += want < avail ? want : avail;
+        }
+        if (__ballot(have) == 0ull) break;
+        // ---- start the next sample of the lane's pixel (rayview.cpp:80-83) ----------------------------
+        if (have && !path) {
+            g.key(ra.seed, pix, uint32_t(s));
+            float u = (float(x) + g.u01()) / float(ra.W);
+            float v = (float(y) + g.u01()) / float(ra.H);
+            ray = get_ray(cam, g, u, v);
+            level = 0; depth_left = ra.depth; path = true;
+        }
+        // ---- one closest-hit scan per lane, then one bounce ------------------------------------------------
+        if (path) {
+            ++n_rays;
+            Hit h = closest_hit(sc, ray, double(0.001f), kInf, words);       // calc.cpp:99
+            if (VERIFY) {
+                Hit h2 = closest_hit_listorder(sc, ray, double(0.001f), kInf);
+                if (h2.prim != h.prim || __double_as_longlong(h2.t) != __double_as_longlong(h.t)) atomicAdd(ra.mismatches, 1ull);
+            }
+            V3 L;
+            bool done = shade_bounce(sc, ray, h, g, normals, st, level, L);
+            if (!done) {
+                ++level; --depth_left;
+                if (depth_left <= 0) { L = v3(0.0f, 0.0f, 0.0f); done = true; }   // calc.cpp:96-97
+            }
+            if (done) {
+                sum = sum + unwind_path(st, level, L);                        // rayview.cpp:83
+                path = false;
+                if (++s == spp_end) {
+                    float4 a = make_float4(sum.x, sum.y, sum.z, float(ra.spp_count));
+                    if (ra.flags & RT_RENDER_ACCUMULATE) {
+                        float4 o = ra.accum[pix];
+                        a = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + float(ra.spp_count));
+                    }
+                    ra.accum[pix] = a;
+                    have = false;
+                }
+            }
+        }
+    }
+    if (ra.rays_out) {
+        unsigned long long v = n_rays;   // per-wave sum, one atomic per wave
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0 && v) atomicAdd(ra.rays_out, v);
+    }
 }
 
-__global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, DevCamera cam, int W, int H, int y_begin, int y_count,
-                                                        int spp_begin, int spp_count, int depth, uint64_t seed, uint32_t flags,
-                                                        float4* __restrict__ accum, float4* __restrict__ stack,
-                                                        unsigned long long* __restrict__ rays_out) {
-    const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (y_count + kTile - 1) / kTile;
-    const int n_tiles = tiles_x * tiles_y;
-    PathStack st; st.base = stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
-    const bool normals = (flags & RT_RENDER_NORMALS) != 0;
-    uint32_t n_rays = 0;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        int x, y;
-        tile_xy(tile, tiles_x, y_begin, x, y);
-        if (x >= W || y >= y_begin + y_count || y >= H) continue;
-        const uint32_t pix = uint32_t(y) * uint32_t(W) + uint32_t(x);
-        V3 sum = v3(0.0f, 0.0f, 0.0f);
-        for (int s = spp_begin; s < spp_begin + spp_count; ++s) {
-            Rng g; g.key(seed, pix, uint32_t(s));
-            float u = (float(x) + g.u01()) / float(W);                       // rayview.cpp:80-81
-            float v = (float(y) + g.u01()) / float(H);
-            Ray ray = get_ray(cam, g, u, v);
-            V3 c = trace_path(sc, ray, g, depth, normals, st, n_rays);        // rayview.cpp:83
-            sum = sum + c;
-        }
-        float4 a = make_float4(sum.x, sum.y, sum.z, float(spp_count));
-        if (flags & RT_RENDER_ACCUMULATE) {
-            float4 o = accum[pix];
-            a = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + float(spp_count));
-        }
-        accum[pix] = a;
+// depth <= 0 or no samples: every sample is black and no ray is traced (calc.cpp:96-97)
+__global__ void render_black_kernel(int W, int y_begin, int y_count, int spp_count, uint32_t flags, float4* __restrict__ accum) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W * y_count) return;
+    size_t pix = size_t(y_begin) * W + i;
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, float(spp_count));
+    if (flags & RT_RENDER_ACCUMULATE) {
+        float4 o = accum[pix];
+        a = make_float4(o.x + 0.0f, o.y + 0.0f, o.z + 0.0f, o.w + float(spp_count));
     }
-    if (rays_out) {
-        // per-wave sum, one atomic per wave
-        unsigned long long v = n_rays;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(rays_out, v);
-    }
+    accum[pix] = a;
 }
 
 __global__ __launch_bounds__(kBlock) void primary_kernel(DevScene sc, DevCamera cam, int W, int H, uint64_t seed,
                                                          int* __restrict__ prim_out, double* __restrict__ t_out) {
-    const int tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
+    __shared__ uint32_t s_words[kMaskWords * kBlock];
+    uint32_t* words = s_words + threadIdx.x;
+    const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
     for (int tile = blockIdx.x; tile < tiles_x * tiles_y; tile += gridDim.x) {
-        int x, y;
-        tile_xy(tile, tiles_x, 0, x, y);
+        const int t = threadIdx.x;
+        const int x = (tile % tiles_x) * 16 + (t & 7) + 8 * ((t >> 6) & 1);
+        const int y = (tile / tiles_x) * 16 + ((t & 63) >> 3) + 8 * (t >> 7);
         if (x >= W || y >= H) continue;
         const uint32_t pix = uint32_t(y) * uint32_t(W) + uint32_t(x);
         Rng g; g.key(seed, pix, 0u);
         float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);
         Ray ray = get_ray(cam, g, u, v);
-        Hit h = closest_hit(sc, ray, double(0.001f), kInf);
+        Hit h = closest_hit(sc, ray, double(0.001f), kInf, words);
         if (prim_out) prim_out[pix] = h.prim;
         if (t_out) t_out[pix] = h.prim >= 0 ? h.t : 0.0;
     }
@@ -416,9 +514,11 @@ __global__ __launch_bounds__(kBlock) void hit_rays_kernel(DevScene sc, long long
                                                           int* __restrict__ prim_out, double* __restrict__ t_out,
                                                           float* __restrict__ p_out, float* __restrict__ n_out,
                                                           uint8_t* __restrict__ ff_out) {
+    __shared__ uint32_t s_words[kMaskWords * kBlock];
+    uint32_t* words = s_words + threadIdx.x;
     for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
         Ray ray = make_ray(v3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), v3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]));
-        Hit h = closest_hit(sc, ray, t_min, t_max);
+        Hit h = closest_hit(sc, ray, t_min, t_max, words);
         prim_out[i] = h.prim;
         if (t_out) t_out[i] = h.prim >= 0 ? h.t : 0.0;
         HitRec rec; rec.p = v3(0, 0, 0); rec.normal = v3(0, 0, 0); rec.front_face = false;
@@ -432,12 +532,13 @@ __global__ __launch_bounds__(kBlock) void hit_rays_kernel(DevScene sc, long long
 __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene sc, long long n, const float* __restrict__ ro,
                                                             const float* __restrict__ rd, int depth, uint64_t seed, uint32_t flags,
                                                             float* __restrict__ rgb, float4* __restrict__ stack) {
+    __shared__ uint32_t s_words[kMaskWords * kBlock];
+    uint32_t* words = s_words + threadIdx.x;
     PathStack st; st.base = stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t n_rays = 0;
     for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
         Ray ray = make_ray(v3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), v3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]));
         Rng g; g.key(seed, uint32_t(i), 0u);
-        V3 c = trace_path(sc, ray, g, depth, (flags & RT_RENDER_NORMALS) != 0, st, n_rays);
+        V3 c = trace_path(sc, ray, g, depth, (flags & RT_RENDER_NORMALS) != 0, st, words);
         rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
     }
 }
@@ -495,6 +596,8 @@ struct Context {
     bool have_cam = false;
     void* stack = nullptr;
     size_t stack_bytes = 0;
+    void* counters = nullptr;   // [0] unsigned int: tile counter of render_kernel; [8] unsigned long long: verify mismatches
+    int render_blocks_per_cu = 0;
 } g;
 
 int need_ready() { return g.ready ? 0 : fail("rt_init() has not bound a HIP device (no CPU fallback exists)"); }
@@ -540,6 +643,11 @@ int rt_init(int device) {
     HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreate(&g.ev0));
     HIP_OK(hipEventCreate(&g.ev1));
+    HIP_OK(hipMalloc(&g.counters, 16));
+    HIP_OK(hipMemset(g.counters, 0, 16));
+    int per_cu = 0;
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false>, kBlock, 0));
+    g.render_blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
     g.device = device;
     g.ready = true;
     return 0;
@@ -552,6 +660,8 @@ void rt_shutdown(void) {
     free_scene();
     if (g.stack) (void)hipFree(g.stack);
     g.stack = nullptr; g.stack_bytes = 0;
+    if (g.counters) (void)hipFree(g.counters);
+    g.counters = nullptr;
     (void)hipEventDestroy(g.ev0); (void)hipEventDestroy(g.ev1);
     (void)hipStreamDestroy(g.stream);
     g.ready = false; g.have_cam = false; g.device = -1;
@@ -627,6 +737,67 @@ int rt_upload_scene(const RtScene* s) {
         s->light_kind != RT_PRIM_XZ_RECT)
         return fail("rt_upload_scene: light kind %d has no pdf_value/random in the reference; pass RT_LIGHT_BASE", s->light_kind);
 
+    // ---- sphere groups (rt_scan.hpp): exact group first, then the filter group in pairs, padded ---------
+    SphereGroups sg{};
+    std::vector<float> fx, fy, fz, fk;
+    std::vector<float4> fq;
+    {
+        const int n = int(sph.size());
+        bool finite = true;
+        for (const float4& q : sph)
+            if (!(std::fabs(q.x) <= 1.0e7f && std::fabs(q.y) <= 1.0e7f && std::fabs(q.z) <= 1.0e7f && std::fabs(q.w) <= 1.0e7f)) finite = false;
+        sg.fast_ok = finite ? 1 : 0;
+        std::vector<char> in_filter(n, 0);
+        double gc[3] = {0, 0, 0};
+        int n_filter = 0;
+        if (finite && n >= 16) {
+            std::vector<double> tmp(n);
+            for (int k = 0; k < 3; ++k) {
+                for (int i = 0; i < n; ++i) tmp[i] = k == 0 ? sph[i].x : (k == 1 ? sph[i].y : sph[i].z);
+                std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
+                gc[k] = double(float(tmp[n / 2]));
+            }
+            std::vector<double> ext(n);
+            for (int i = 0; i < n; ++i) {
+                double dx = sph[i].x - gc[0], dy = sph[i].y - gc[1], dz = sph[i].z - gc[2];
+                ext[i] = std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs(double(sph[i].w));
+            }
+            tmp = ext;
+            std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
+            const double thr = std::min(8.0 * tmp[n / 2], 0.5e6);
+            for (int i = 0; i < n; ++i) if (ext[i] <= thr) { in_filter[i] = 1; ++n_filter; }
+            if (n_filter < 16 || std::fabs(gc[0]) > 0.5e6 || std::fabs(gc[1]) > 0.5e6 || std::fabs(gc[2]) > 0.5e6) {
+                std::fill(in_filter.begin(), in_filter.end(), 0); n_filter = 0;
+            }
+        }
+        std::vector<float4> sph2; std::vector<int> prim2;
+        for (int i = 0; i < n; ++i) if (!in_filter[i]) { prim_local[sph_prim[i]] = int(sph2.size()); sph2.push_back(sph[i]); prim2.push_back(sph_prim[i]); }
+        sg.n_exact = int(sph2.size());
+        double cmax = 0, r2max = 0;
+        for (int i = 0; i < n; ++i) if (in_filter[i]) {
+            prim_local[sph_prim[i]] = int(sph2.size()); sph2.push_back(sph[i]); prim2.push_back(sph_prim[i]);
+            const float rx = float(sph[i].x - gc[0]), ry = float(sph[i].y - gc[1]), rz = float(sph[i].z - gc[2]);
+            const float r2 = sph[i].w * sph[i].w;   // radiusSquared, shapes.h:73
+            const double c2 = double(rx) * rx + double(ry) * ry + double(rz) * rz;
+            fx.push_back(rx); fy.push_back(ry); fz.push_back(rz); fk.push_back(float(c2 - double(r2)));
+            cmax = std::max(cmax, std::sqrt(c2)); r2max = std::max(r2max, double(r2));
+        }
+        const float nanf_ = std::numeric_limits<float>::quiet_NaN();
+        while (fx.size() % 16 != 0) {   // pads: never flagged (k huge), never a candidate (NaN centre)
+            fx.push_back(0.0f); fy.push_back(0.0f); fz.push_back(0.0f); fk.push_back(3.0e38f);
+            sph2.push_back(make_float4(nanf_, nanf_, nanf_, 1.0f)); prim2.push_back(-1);
+        }
+        sg.n_fpairs = int(fx.size() / 2);
+        for (int pr = 0; pr < sg.n_fpairs; ++pr) {
+            const float4 s0 = sph2[sg.n_exact + 2 * pr], s1 = sph2[sg.n_exact + 2 * pr + 1];
+            fq.push_back(make_float4(s0.x, s1.x, s0.y, s1.y));
+            fq.push_back(make_float4(s0.z, s1.z, s0.w * s0.w, s1.w * s1.w));
+        }
+        sg.gx = float(gc[0]); sg.gy = float(gc[1]); sg.gz = float(gc[2]);
+        sg.cmax = float(cmax * 1.000001) + 1.0e-30f; sg.r2max = float(r2max * 1.000001);
+        sph.swap(sph2); sph_prim.swap(prim2);
+    }
+
     HIP_OK(hipStreamSynchronize(g.stream));
     free_scene();
     DevScene ds{};
@@ -639,6 +810,8 @@ int rt_upload_scene(const RtScene* s) {
     std::vector<float> mrgb(s->mat_rgb, s->mat_rgb + 3 * size_t(s->n_mats)), mf(s->mat_fuzz, s->mat_fuzz + s->n_mats);
     std::vector<double> mir(s->mat_ir, s->mat_ir + s->n_mats);
     if (upload(mk, &ds.mat_kind) || upload(mrgb, &ds.mat_rgb) || upload(mf, &ds.mat_fuzz) || upload(mir, &ds.mat_ir)) return 1;
+    if (upload(fx, &sg.fx) || upload(fy, &sg.fy) || upload(fz, &sg.fz) || upload(fk, &sg.fk) || upload(fq, &sg.fq)) return 1;
+    ds.sg = sg;
     ds.light_kind = s->light_kind;
     for (int k = 0; k < 3; ++k) ds.light_c[k] = float(s->light_data[k]);
     ds.light_r = float(s->light_data[3]);
@@ -701,7 +874,7 @@ static int finish_timed(int launches) {
 int rt_primary_hits(int w, int h, uint64_t seed, int32_t* d_prim, double* d_t) {
     if (need_scene_cam()) return 1;
     if (w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL) return fail("rt_primary_hits: bad size %dx%d", w, h);
-    int n_tiles = ((w + kTile - 1) / kTile) * ((h + kTile - 1) / kTile);
+    int n_tiles = ((w + 15) / 16) * ((h + 15) / 16);
     HIP_OK(hipEventRecord(g.ev0, g.stream));
     hipLaunchKernelGGL(primary_kernel, dim3(grid_for(n_tiles)), dim3(kBlock), 0, g.stream, g.scene, g.cam, w, h, seed, d_prim, d_t);
     return finish_timed(1);
@@ -755,14 +928,39 @@ int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_cou
     if (depth < 0 || depth > 128) return fail("rt_render: depth %d outside 0..128", depth);
     if (!d_accum) return fail("rt_render: null accumulator");
     if (y_count == 0) { g.last_ms = 0; g.last_launches = 0; return 0; }
-    int n_tiles = ((w + kTile - 1) / kTile) * ((y_count + kTile - 1) / kTile);
-    int grid = grid_for(n_tiles);
+    if (spp_count == 0 || depth == 0) {   // no ray is traced: every sample is black (calc.cpp:96-97)
+        int n = w * y_count;
+        HIP_OK(hipEventRecord(g.ev0, g.stream));
+        hipLaunchKernelGGL(render_black_kernel, dim3((n + 255) / 256), dim3(256), 0, g.stream, w, y_begin, y_count, spp_count, flags,
+                           reinterpret_cast<float4*>(d_accum));
+        return finish_timed(1);
+    }
+    const int n_tiles = ((w + kTile - 1) / kTile) * ((y_count + kTile - 1) / kTile);   // one 8x8 tile per wave at a time
+    const int resident = g.prop.multiProcessorCount * g.render_blocks_per_cu;
+    const int want = (n_tiles + 3) / 4;
+    const int grid = want < resident ? want : resident;
     if (ensure_stack(depth, grid)) return 1;
+    RenderArgs ra{};
+    ra.W = w; ra.H = h; ra.y_begin = y_begin; ra.y_count = y_count; ra.spp_begin = spp_begin; ra.spp_count = spp_count; ra.depth = depth;
+    ra.seed = seed; ra.flags = flags;
+    ra.accum = reinterpret_cast<float4*>(d_accum); ra.stack = static_cast<float4*>(g.stack);
+    ra.rays_out = reinterpret_cast<unsigned long long*>(d_rays);
+    ra.work_counter = static_cast<unsigned int*>(g.counters);
+    ra.mismatches = reinterpret_cast<unsigned long long*>(static_cast<char*>(g.counters) + 8);
+    const bool verify = (flags & RT_RENDER_VERIFY) != 0;
+    HIP_OK(hipMemsetAsync(g.counters, 0, verify ? 16 : 4, g.stream));
     HIP_OK(hipEventRecord(g.ev0, g.stream));
-    hipLaunchKernelGGL(render_kernel, dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, w, h, y_begin, y_count, spp_begin,
-                       spp_count, depth, seed, flags, reinterpret_cast<float4*>(d_accum), static_cast<float4*>(g.stack),
-                       reinterpret_cast<unsigned long long*>(d_rays));
+    if (verify) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
+    else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
     return finish_timed(1);
+}
+
+int rt_verify_mismatches(uint64_t* count) {
+    if (need_ready()) return 1;
+    if (!count) return fail("rt_verify_mismatches: null argument");
+    HIP_OK(hipMemcpyAsync(count, static_cast<char*>(g.counters) + 8, 8, hipMemcpyDeviceToHost, g.stream));
+    HIP_OK(hipStreamSynchronize(g.stream));
+    return 0;
 }
 
 int rt_tonemap(int w, int h, const float* d_accum, int n_samples, uint32_t* d_rgb32) {

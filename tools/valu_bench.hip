@@ -1,0 +1,74 @@
+// Microbenchmark: issue rate of plain vs packed FP32 VALU on gfx950 (one-off measurement that fixes
+// the instruction budget of the closest-hit loop; see DESIGN.md "VALU issue model").
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define N_ITER 16384
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* out, float seed) {
+    float a0 = threadIdx.x * 1e-3f + seed, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float m = 1.0000001f;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pm = {m, m};
+    for (int i = 0; i < N_ITER; ++i) {
+      _Pragma("unroll") for (int rep = 0; rep < 4; ++rep) {
+        if (MODE == 0) {   // 8 independent v_mul_f32
+            asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                         "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+        } else if (MODE == 1) {   // 4 independent v_pk_mul_f32 (8 multiplies)
+            asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pm));
+        } else if (MODE == 2) {   // 8 v_fma_f32
+            asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                         "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+        } else if (MODE == 3) {   // 4 v_pk_add_f32
+            asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pm));
+        } else if (MODE == 4) {   // 8 v_add_f32 with an SGPR operand
+            asm volatile("v_add_f32 %0, %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"
+                         "v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(seed));
+        } else if (MODE == 5) {   // 4 v_pk_fma_f32
+            asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pm));
+        } else if (MODE == 6) {   // 8 v_alignbit_b32 (VOP3, 3 operands)
+            asm volatile("v_alignbit_b32 %0, %0, %8, 31\n v_alignbit_b32 %1, %1, %8, 31\n v_alignbit_b32 %2, %2, %8, 31\n v_alignbit_b32 %3, %3, %8, 31\n"
+                         "v_alignbit_b32 %4, %4, %8, 31\n v_alignbit_b32 %5, %5, %8, 31\n v_alignbit_b32 %6, %6, %8, 31\n v_alignbit_b32 %7, %7, %8, 31\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+        } else if (MODE == 7) {   // 8 v_mul_f64? use 4 v_fma_f64
+            double d0 = a0, d1 = a1, d2 = a2, d3 = a3, dm = m;
+            asm volatile("v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4\n"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dm));
+            a0 = d0; a1 = d1; a2 = d2; a3 = d3;
+        }
+      }
+    }
+    float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+    if (r == 12345.678f) out[0] = r;
+}
+template <int MODE>
+void run(const char* name, int ops_per_iter, float* d) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    int grid = 256 * 8;   // 8 blocks of 4 waves per CU = 8 waves/SIMD
+    k<MODE><<<grid, 256>>>(d, 0.5f);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) k<MODE><<<grid, 256>>>(d, 0.5f);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    double lane_ops = double(grid) * 256 * N_ITER * 4.0 * ops_per_iter;
+    printf("%-28s %8.3f ms  %7.2f T lane-ops/s (elementwise results/s)\n", name, ms, lane_ops / (ms * 1e-3) / 1e12);
+}
+int main() {
+    float* d; hipMalloc(&d, 4);
+    run<0>("v_mul_f32 x8", 8, d);
+    run<1>("v_pk_mul_f32 x4 (8 mul)", 8, d);
+    run<2>("v_fma_f32 x8", 8, d);
+    run<3>("v_pk_add_f32 x4 (8 add)", 8, d);
+    run<4>("v_add_f32 sgpr x8", 8, d);
+    run<5>("v_pk_fma_f32 x4 (8 fma)", 8, d);
+    run<6>("v_alignbit_b32 x8", 8, d);
+    run<7>("v_fma_f64 x4 (+cvt)", 4, d);
+    return 0;
+}
