@@ -155,13 +155,13 @@ __device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const R
 // Fast scan: spheres through rt_scan.hpp (filter + exact), then rects and triangles. Lanes whose ray
 // is outside the fast range (non-finite, huge, zero direction), a scene that is, or a NaN t from a
 // rect, fall back to the list-order scan, which is the reference loop itself.
-__device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, double t_min, double t_max, uint32_t* words) {
+__device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, double t_min, double t_max, uint32_t* words RT_STAMP_PARAM) {
     Hit h; h.t = t_max; h.prim = -1;
     bool ok = sc.sg.fast_ok && ray_in_fast_range(r.o, r.d, r.dl2) && t_min == t_min && t_max == t_max;
     if (ok) {
         HitState hs; hs.bt = t_max; hs.bi = -1; hs.btf = __double2float_ru(t_max);
         const float tminf = __double2float_rd(t_min);
-        scan_spheres(sc.sg, sc.sph, sc.sph_prim, r.o, r.d, r.dl2, t_min, tminf, hs, words);
+        scan_spheres(sc.sg, sc.sph, sc.sph_prim, r.o, r.d, r.dl2, t_min, tminf, hs, words RT_STAMP_ARG);
         h.t = hs.bt; h.prim = hs.bi;
         bool saw_nan = false;
         for (int j = 0; j < sc.n_rect; ++j) {
@@ -179,6 +179,7 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
         ok = !saw_nan;
     }
     if (!ok) h = closest_hit_listorder(sc, r, t_min, t_max);
+    RT_STAMP(4);
     return h;
 }
 
@@ -333,24 +334,37 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const
     return false;
 }
 
-// Unwind `level` pushed bounces from the terminal radiance L, innermost first.
+// Unwind `level` pushed bounces from the terminal radiance L, innermost first. The stack entries are
+// fetched four at a time so that a path pays one HBM round trip per four levels, not one per level.
+RT_DEV V3 unwind_step(float4 e, V3 L) {
+    V3 w = v3(e.x, e.y, e.z);
+    if (e.w == kSpecularMark) return w * L;                                  // calc.cpp:119-120
+    return v3(0.0f, 0.0f, 0.0f) + w * L / e.w;                               // calc.cpp:129-130 (emitted == 0)
+}
 __device__ __forceinline__ V3 unwind_path(const PathStack& st, int level, V3 L) {
     while (level > 0) {
-        --level;
-        float4 e = st.get(level);
-        V3 w = v3(e.x, e.y, e.z);
-        if (e.w == kSpecularMark) L = w * L;                                 // calc.cpp:119-120
-        else L = v3(0.0f, 0.0f, 0.0f) + w * L / e.w;                         // calc.cpp:129-130 (emitted == 0)
+        const float4 e0 = st.get(level - 1);
+        const float4 e1 = st.get(level > 1 ? level - 2 : 0);
+        const float4 e2 = st.get(level > 2 ? level - 3 : 0);
+        const float4 e3 = st.get(level > 3 ? level - 4 : 0);
+        L = unwind_step(e0, L);
+        if (level > 1) L = unwind_step(e1, L);
+        if (level > 2) L = unwind_step(e2, L);
+        if (level > 3) L = unwind_step(e3, L);
+        level -= 4;
     }
     return L;
 }
 
 // ray_color for one ray, simple per-thread loop (rt_trace_rays).
 __device__ __forceinline__ V3 trace_path(const DevScene& sc, Ray ray, Rng& g, int depth, bool normals, PathStack& st, uint32_t* words) {
+#ifdef RT_STAMPS
+    Stamps stp{};
+#endif
     int level = 0;
     V3 L = v3(0.0f, 0.0f, 0.0f);
     for (int depth_left = depth; depth_left > 0; --depth_left) {            // depth_left <= 0: black, calc.cpp:96-97
-        Hit h = closest_hit(sc, ray, double(0.001f), kInf, words);           // calc.cpp:99
+        Hit h = closest_hit(sc, ray, double(0.001f), kInf, words RT_STAMP_ARG);   // calc.cpp:99
         if (shade_bounce(sc, ray, h, g, normals, st, level, L)) break;
         ++level;
         L = v3(0.0f, 0.0f, 0.0f);
@@ -373,6 +387,7 @@ struct RenderArgs {
     unsigned long long* __restrict__ rays_out;
     unsigned int* __restrict__ work_counter;       // next tile to hand out, zeroed before the launch
     unsigned long long* __restrict__ mismatches;   // VERIFY builds: scans whose fast result differs from the list-order scan
+    unsigned long long* stamps;                    // RT_STAMPS diagnostic builds: [12] section cycles and pass counts
 };
 
 // Persistent waves with path regeneration. Every lane owns one pixel at a time and walks its samples
@@ -400,6 +415,10 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, DevCamera c
     Rng g; g.state = 0;
     int q_cur = 0, q_end = 0;      // wave-uniform: the wave's queue of work indices
     bool exhausted = false;        // wave-uniform: the global counter has run past the last tile
+#ifdef RT_STAMPS
+    Stamps stp{};
+    stp.last = __builtin_amdgcn_s_memtime();
+#endif
 
     for (;;) {
         // ---- hand pixels to idle lanes ------------------------------------------------------------
@@ -440,10 +459,12 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, DevCamera c
             ray = get_ray(cam, g, u, v);
             level = 0; depth_left = ra.depth; path = true;
         }
+        RT_STAMP(0);
+        RT_COUNT(3);
         // ---- one closest-hit scan per lane, then one bounce ------------------------------------------------
         if (path) {
             ++n_rays;
-            Hit h = closest_hit(sc, ray, double(0.001f), kInf, words);       // calc.cpp:99
+            Hit h = closest_hit(sc, ray, double(0.001f), kInf, words RT_STAMP_ARG);   // calc.cpp:99
             if (VERIFY) {
                 Hit h2 = closest_hit_listorder(sc, ray, double(0.001f), kInf);
                 if (h2.prim != h.prim || __double_as_longlong(h2.t) != __double_as_longlong(h.t)) atomicAdd(ra.mismatches, 1ull);
@@ -454,6 +475,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, DevCamera c
                 ++level; --depth_left;
                 if (depth_left <= 0) { L = v3(0.0f, 0.0f, 0.0f); done = true; }   // calc.cpp:96-97
             }
+            RT_STAMP(5);
             if (done) {
                 sum = sum + unwind_path(st, level, L);                        // rayview.cpp:83
                 path = false;
@@ -467,8 +489,15 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, DevCamera c
                     have = false;
                 }
             }
+            RT_STAMP(6);
         }
     }
+#ifdef RT_STAMPS
+    if (ra.stamps) {
+        for (int k = 0; k < 8; ++k) if (lane == 0) atomicAdd(ra.stamps + k, stp.t[k]);
+        for (int k = 0; k < 4; ++k) atomicAdd(ra.stamps + 8 + k, (unsigned long long)stp.cnt[k]);
+    }
+#endif
     if (ra.rays_out) {
         unsigned long long v = n_rays;   // per-wave sum, one atomic per wave
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -503,7 +532,10 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(DevScene sc, DevCamera 
         Rng g; g.key(seed, pix, 0u);
         float u = (float(x) + 0.5f) / float(W), v = (float(y) + 0.5f) / float(H);
         Ray ray = get_ray(cam, g, u, v);
-        Hit h = closest_hit(sc, ray, double(0.001f), kInf, words);
+#ifdef RT_STAMPS
+        Stamps stp{};
+#endif
+        Hit h = closest_hit(sc, ray, double(0.001f), kInf, words RT_STAMP_ARG);
         if (prim_out) prim_out[pix] = h.prim;
         if (t_out) t_out[pix] = h.prim >= 0 ? h.t : 0.0;
     }
@@ -518,7 +550,10 @@ __global__ __launch_bounds__(kBlock) void hit_rays_kernel(DevScene sc, long long
     uint32_t* words = s_words + threadIdx.x;
     for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
         Ray ray = make_ray(v3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), v3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]));
-        Hit h = closest_hit(sc, ray, t_min, t_max, words);
+#ifdef RT_STAMPS
+        Stamps stp{};
+#endif
+        Hit h = closest_hit(sc, ray, t_min, t_max, words RT_STAMP_ARG);
         prim_out[i] = h.prim;
         if (t_out) t_out[i] = h.prim >= 0 ? h.t : 0.0;
         HitRec rec; rec.p = v3(0, 0, 0); rec.normal = v3(0, 0, 0); rec.front_face = false;
@@ -643,8 +678,8 @@ int rt_init(int device) {
     HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
     HIP_OK(hipEventCreate(&g.ev0));
     HIP_OK(hipEventCreate(&g.ev1));
-    HIP_OK(hipMalloc(&g.counters, 16));
-    HIP_OK(hipMemset(g.counters, 0, 16));
+    HIP_OK(hipMalloc(&g.counters, 128));
+    HIP_OK(hipMemset(g.counters, 0, 128));
     int per_cu = 0;
     HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false>, kBlock, 0));
     g.render_blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
@@ -948,12 +983,28 @@ int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_cou
     ra.work_counter = static_cast<unsigned int*>(g.counters);
     ra.mismatches = reinterpret_cast<unsigned long long*>(static_cast<char*>(g.counters) + 8);
     const bool verify = (flags & RT_RENDER_VERIFY) != 0;
+#ifdef RT_STAMPS
+    ra.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(g.counters) + 16);
+    HIP_OK(hipMemsetAsync(g.counters, 0, 128, g.stream));
+#else
+    ra.stamps = nullptr;
     HIP_OK(hipMemsetAsync(g.counters, 0, verify ? 16 : 4, g.stream));
+#endif
     HIP_OK(hipEventRecord(g.ev0, g.stream));
     if (verify) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
     else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
     return finish_timed(1);
 }
+
+#ifdef RT_STAMPS
+// diagnostic builds only (tools/): section cycles and pass counts of the last render
+int rt_debug_stamps(uint64_t out[12]) {
+    if (need_ready()) return 1;
+    HIP_OK(hipMemcpyAsync(out, static_cast<char*>(g.counters) + 16, 96, hipMemcpyDeviceToHost, g.stream));
+    HIP_OK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+#endif
 
 int rt_verify_mismatches(uint64_t* count) {
     if (need_ready()) return 1;

@@ -32,11 +32,47 @@ RT_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x *
 RT_DEV float length_squared(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
 RT_DEV double len2_f64(V3 v) { return double(v.x) * double(v.x) + double(v.y) * double(v.y) + double(v.z) * double(v.z); }
 RT_DEV float length(V3 v) { return float(__builtin_sqrt(len2_f64(v))); }
+// IEEE double division with the reciprocal of the divisor shared between several numerators. The
+// operations are the ones hipcc emits for `n / d` on gfx950 (v_rcp_f64, two Newton steps on the
+// reciprocal, quotient, exact remainder, one correction) minus v_div_scale / v_div_fixup, which only
+// act on operands near the ends of the exponent range; callers guard those and use `/` there.
+struct Recip64 {
+    double d, r;
+};
+RT_DEV Recip64 recip64(double d) {
+    Recip64 R; R.d = d;
+#ifdef __HIP_DEVICE_COMPILE__
+    double r0 = __builtin_amdgcn_rcp(d);
+    double e0 = __builtin_fma(-d, r0, 1.0);
+    double r1 = __builtin_fma(r0, e0, r0);
+    double e1 = __builtin_fma(-d, r1, 1.0);
+    R.r = __builtin_fma(r1, e1, r1);
+#else
+    R.r = 1.0 / d;
+#endif
+    return R;
+}
+// n / R.d for |n| <= 1e300 (or NaN) and R.d in the guarded range of the caller
+RT_DEV double div64(double n, const Recip64& R) {
+#ifdef __HIP_DEVICE_COMPILE__
+    double q = n * R.r;
+    double rem = __builtin_fma(-R.d, q, n);
+    return __builtin_fma(rem, R.r, q);
+#else
+    return n / R.d;
+#endif
+}
+RT_DEV bool recip_range_ok(double d) { return d >= 1.0e-150 && d <= 1.0e150; }   // false for NaN, 0, inf, negative
+
 RT_DEV V3 normalized(V3 v) {
     double len = len2_f64(v);
     if (__builtin_fabs(len - 1.0) <= 0.000000000001) return v;
     if (!(__builtin_fabs(len) <= 0.000000000001)) {
         double s = __builtin_sqrt(len);
+        if (recip_range_ok(s)) {   // always, unless a component is inf / NaN
+            Recip64 R = recip64(s);
+            return v3(float(div64(double(v.x), R)), float(div64(double(v.y), R)), float(div64(double(v.z), R)));
+        }
         return v3(float(double(v.x) / s), float(double(v.y) / s), float(double(v.z) / s));
     }
     return v3(0.0f, 0.0f, 0.0f);

@@ -47,6 +47,25 @@ struct SphereGroups {
     int fast_ok;                     // 0: some sphere is non-finite / out of range -> list-order scan only
 };
 
+// Diagnostic build only (-DRT_STAMPS): cycles per section of the render loop (s_memtime, wave-uniform)
+// and wave-level pass counts of the divergent loops. Never compiled into the product library.
+#ifdef RT_STAMPS
+struct Stamps {
+    unsigned long long t[8];     // 0 assign+new sample, 1 exact group, 2 filter, 3 candidate walk, 4 rect+tri, 5 shade, 6 unwind+store, 7 other
+    unsigned long long last;
+    unsigned int cnt[4];         // per lane, counted on the first active lane only: 0 walk passes, 1 FP64 root passes, 2 exact-group FP64 passes, 3 scans
+};
+#define RT_STAMP(i) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); stp.t[i] += now_ - stp.last; stp.last = now_; } while (0)
+#define RT_COUNT(i) do { if ((__ffsll((long long)__ballot(1)) - 1) == int(threadIdx.x & 63)) ++stp.cnt[i]; } while (0)
+#define RT_STAMP_PARAM , Stamps& stp
+#define RT_STAMP_ARG , stp
+#else
+#define RT_STAMP(i) do {} while (0)
+#define RT_COUNT(i) do {} while (0)
+#define RT_STAMP_PARAM
+#define RT_STAMP_ARG
+#endif
+
 struct HitState {
     double bt;    // closest_so_far (hitPosition.cpp:9)
     int bi;       // its flattened primitive index, -1 = none
@@ -59,7 +78,7 @@ RT_DEV bool reject_t(double t, double t_min, double bt, int idx, int bi) {
 
 // A sphere whose reference discriminant D is >= 0 (a > 0, everything finite): the reference's roots
 // (shapes.h:90-97) in FP64 unless FP32 bounds on them show that both are rejected.
-__device__ __forceinline__ void sphere_candidate(float a, float b, float D, int idx, double t_min, float tminf, HitState& h) {
+__device__ __forceinline__ void sphere_candidate(float a, float b, float D, int idx, double t_min, float tminf, HitState& h RT_STAMP_PARAM, int cnt_slot = 1) {
     float nb = -b;
     float ia = __builtin_amdgcn_rcpf(a);
     float sf = __builtin_amdgcn_sqrtf(D);
@@ -67,6 +86,9 @@ __device__ __forceinline__ void sphere_candidate(float a, float b, float D, int 
     float lo1 = (nb - sf) * ia - e;                        // lower bound of the near root
     float hi2 = (nb + sf) * ia + e;                        // upper bound of the far root
     if (lo1 > h.btf || hi2 < tminf) return;                // near root > closest_so_far, or far root < t_min
+#ifdef RT_STAMPS
+    if (cnt_slot == 1) RT_COUNT(1); else RT_COUNT(2);
+#endif
     double sqrtd = __builtin_sqrt(double(D));
     double root = (double(nb) - sqrtd) / double(a);
     if (reject_t(root, t_min, h.bt, idx, h.bi)) {
@@ -86,7 +108,7 @@ RT_DEV bool ray_in_fast_range(V3 o, V3 d, float a) {
 // column of the block's flag-word array in LDS (stride kScanBlock). sph / sph_prim: (cx,cy,cz,r) and
 // flattened index per sphere, exact group first. Requires ray_in_fast_range and sg.fast_ok.
 __device__ __forceinline__ void scan_spheres(const SphereGroups& sg, const float4* __restrict__ sph, const int* __restrict__ sph_prim,
-                                             V3 o, V3 d, float a, double t_min, float tminf, HitState& h, uint32_t* words) {
+                                             V3 o, V3 d, float a, double t_min, float tminf, HitState& h, uint32_t* words RT_STAMP_PARAM) {
     // ---- exact group: reference arithmetic on every sphere ------------------------------------------
     for (int j = 0; j < sg.n_exact; ++j) {
         cfp q = RT_CONST_F(sph + j);
@@ -95,8 +117,9 @@ __device__ __forceinline__ void scan_spheres(const SphereGroups& sg, const float
         float b = dot(oc, d);
         float c = length_squared(oc) - r * r;
         float D = b * b - a * c;
-        if (D >= 0.0f) sphere_candidate(a, b, D, sph_prim[j], t_min, tminf, h);
+        if (D >= 0.0f) sphere_candidate(a, b, D, sph_prim[j], t_min, tminf, h RT_STAMP_ARG, 2);
     }
+    RT_STAMP(1);
     if (sg.n_fpairs == 0) return;
     // ---- filter constants of this ray -----------------------------------------------------------------
     V3 orel = o - v3(sg.gx, sg.gy, sg.gz);
@@ -142,10 +165,12 @@ __device__ __forceinline__ void scan_spheres(const SphereGroups& sg, const float
             words[w * kScanBlock] = flagged;
             summary |= (flagged != 0u ? 1u : 0u) << w;
         }
+        RT_STAMP(2);
         // ---- level 2: each lane walks its own flagged pairs ---------------------------------------------
         uint32_t cur = 0;
         int wbase = 0;
         while (cur != 0u || summary != 0u) {
+            RT_COUNT(0);
             if (cur == 0u) {
                 const int w = __builtin_ctz(summary);
                 summary &= summary - 1u;
@@ -166,9 +191,10 @@ __device__ __forceinline__ void scan_spheres(const SphereGroups& sg, const float
             while (pend != 0u) {
                 const bool second = (pend & 1u) == 0u;
                 pend &= pend - 1u;
-                sphere_candidate(a, second ? b.y : b.x, second ? D.y : D.x, sph_prim[j + (second ? 1 : 0)], t_min, tminf, h);
+                sphere_candidate(a, second ? b.y : b.x, second ? D.y : D.x, sph_prim[j + (second ? 1 : 0)], t_min, tminf, h RT_STAMP_ARG);
             }
         }
+        RT_STAMP(3);
     }
 }
 

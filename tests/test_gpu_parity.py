@@ -138,6 +138,25 @@ def test_radiance_sums_bit_exact_vs_oracle(rt, name, kw, W, H, spp, depth):
         assert np.isnan(oacc).any()
 
 
+@pytest.mark.parametrize("name,kw,W,H,spp,depth", [
+    ("random", {"half": 11}, 960, 540, 4, 8),
+    ("builtin", {}, 640, 360, 8, 10),
+    ("mixed", {"half": 5, "n": 9}, 320, 180, 2, 8),
+])
+def test_fast_scan_equals_list_order_scan_at_scale(rt, name, kw, W, H, spp, depth):
+    """RT_RENDER_VERIFY: every closest-hit scan of the frame (millions of primary and bounce rays) is
+    repeated on the device as the reference's list-order loop (hitPosition.cpp:6-22); the sphere
+    filter + exact path of rt_scan.hpp must give the same primitive and the same t bits every time,
+    and the verified frame must equal the plain one."""
+    sc = scenes.get_scene(name, **kw)
+    rt.upload_scene(sc)
+    acc, rays = rt.render(W, H, spp, depth, seed=0xBEEF)
+    acc_v, rays_v = rt.render(W, H, spp, depth, seed=0xBEEF, flags=4)
+    assert rt.verify_mismatches() == 0
+    assert rays == rays_v and rays > W * H * spp
+    assert O.same_values(acc, acc_v)
+
+
 def test_render_edge_cases(rt):
     sc = scenes.builtin_scene()
     rt.upload_scene(sc)

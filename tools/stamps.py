@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Diagnostic: render a workload with the RT_STAMPS build of the library (tools/libray_amd_stamps.so,
+built by hand with -DRT_STAMPS) and print the cycle share of each section of the render loop.
+    python tools/stamps.py [workload] [spp]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ray_amd import api, scenes  # noqa: E402
+import bench  # noqa: E402
+
+wl = dict(bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c3"])
+spp = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+ctx = api.Context(0, lib_path=os.path.join(ROOT, "tools", "libray_amd_stamps.so"))
+scene = scenes.get_scene(wl["scene"], **wl["kw"])
+ctx.upload_scene(scene)
+W, H = wl["W"], wl["H"]
+acc = ctx.alloc(W * H * 16).zero()
+rays = ctx.alloc(8).zero()
+for _ in range(2):
+    rays.zero()
+    ctx.render_into(W, H, acc, spp, wl["depth"], seed=1, rays=rays)
+ms, _ = ctx.last_kernel_ms()
+out = (C.c_uint64 * 12)()
+ctx.lib.rt_debug_stamps.argtypes = [C.POINTER(C.c_uint64)]
+ctx.lib.rt_debug_stamps(out)
+t = list(out)
+n_rays = int(rays.to_numpy("uint64", (1,))[0])
+names = ["assign+new sample", "exact group", "filter", "candidate walk", "rect+tri(+fallback)", "shade", "unwind+store", "other"]
+tot = sum(t[:8])
+print(f"{wl['desc']} at {spp} spp: {ms:.2f} ms, {n_rays / ms / 1e3:.0f} Mrays/s (stamped build; read shares, not speed)")
+scans = t[11]
+for n, v in zip(names, t[:8]):
+    print(f"  {n:22s} {100.0 * v / tot:6.2f} %   {v / max(scans, 1):9.0f} cycles per wave-scan")
+print(f"  wave-scans {scans}, rays per wave-scan {n_rays / max(scans, 1):.1f} (64 = all lanes busy)")
+print(f"  walk passes per wave-scan {t[8] / max(scans, 1):.2f}, FP64 root passes {t[9] / max(scans, 1):.2f}, exact-group FP64 passes {t[10] / max(scans, 1):.2f}")
+ctx.close()
