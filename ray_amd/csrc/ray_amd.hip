@@ -40,6 +40,7 @@ struct DevScene {
     const float* __restrict__ mat_rgb;     // [n_mats][3]
     const float* __restrict__ mat_fuzz;    // [n_mats]
     const double* __restrict__ mat_ir;     // [n_mats]
+    const double* __restrict__ mat_inv_ir; // [n_mats] 1.0 / ir (host IEEE division, hitPosition.h:256)
     int light_kind;                        // RT_LIGHT_BASE, RT_PRIM_SPHERE, RT_PRIM_XY_RECT, RT_PRIM_XZ_RECT
     float light_c[3], light_r;             // sphere light
     double light_rect[5];                  // rect light
@@ -213,9 +214,24 @@ __device__ __forceinline__ HitRec hit_record(const DevScene& sc, const Ray& r, c
 __device__ __forceinline__ double light_pdf_value(const DevScene& sc, V3 o, V3 v) {
     if (sc.light_kind == RT_PRIM_SPHERE) {
         Ray r = make_ray(o, v);
-        double t;
         float4 s = make_float4(sc.light_c[0], sc.light_c[1], sc.light_c[2], sc.light_r);
-        if (!sphere_t(r, s, 0.001, kInf, 0, -1, &t)) return 0.0;
+        // sphere::hit(Ray(o, v), 0.001, infinity) is only asked WHETHER it hits (shapes.h:119-121): FP32
+        // bounds on the roots decide it unless a root is within rounding of 0.001
+        V3 oc = r.o - v3(s.x, s.y, s.z);
+        float a = r.dl2, b = dot(oc, r.d), c = length_squared(oc) - s.w * s.w;
+        float D = b * b - a * c;
+        int verdict = -1;   // 1 hit, 0 miss, -1 undecided
+        if (a >= kMinA && a <= kMaxA && __builtin_fabsf(b) <= 1.0e18f && __builtin_fabsf(D) <= 1.0e36f) {
+            if (D < 0.0f) verdict = 0;
+            else {
+                float nb = -b, ia = __builtin_amdgcn_rcpf(a), sf = __builtin_amdgcn_sqrtf(D);
+                float e = (__builtin_fabsf(nb) + sf) * ia * 2.0e-6f;
+                if ((nb - sf) * ia - e > 0.0010001f) verdict = 1;          // near root certainly >= t_min
+                else if ((nb + sf) * ia + e < 0.0009999f) verdict = 0;     // far root certainly < t_min
+            }
+        }
+        if (verdict < 0) { double t; verdict = sphere_t(r, s, 0.001, kInf, 0, -1, &t) ? 1 : 0; }
+        if (verdict == 0) return 0.0;
         V3 co = v3(s.x, s.y, s.z) - o;
         double cos_theta_max = __builtin_sqrt(double(1 - s.w * s.w / length_squared(co)));
         double solid_angle = 2 * kPi * (1 - cos_theta_max);
@@ -272,11 +288,17 @@ struct PathStack {
 };
 constexpr float kSpecularMark = -1.0f;
 
+// double(x) / pi with the reciprocal of pi refined once per kernel (recip64); `/` for inf and NaN
+RT_DEV double div_by_pi(float x, const Recip64& rpi) {
+    if (__builtin_fabsf(x) <= 3.0e38f) return div64(double(x), rpi);
+    return double(x) / kPi;
+}
+
 // One bounce: the body of ray_color after hitFromList returned `h` for `ray`. Returns true when the
 // path ends here with terminal radiance L (miss, light, normal view); otherwise pushes this level's
 // weight and replaces `ray` by the scattered / specular ray.
 __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const Hit& h, Rng& g, bool normals, PathStack& st, int level,
-                                             V3& L) {
+                                             const Recip64& rpi, V3& L) {
     if (h.prim < 0) { L = v3(sc.bg[0], sc.bg[1], sc.bg[2]); return true; }      // calc.cpp:100-103
     if (normals) {                                                          // calc.cpp:105-109
         V3 N = normalized(ray_at(ray, h.t) - v3(0.0f, 0.0f, -1.0f));
@@ -290,15 +312,15 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const
     if (mk == RT_MAT_DIFFUSE_LIGHT) { L = rgb; return true; }                // hitPosition.h:301-310, calc.cpp:115-116
     V3 w;
     float pdf = kSpecularMark;
+    V3 unit_direction = v3(0.0f, 0.0f, 0.0f);
+    if (mk == RT_MAT_METAL || mk == RT_MAT_DIELECTRIC) unit_direction = normalized(ray.d);   // hitPosition.h:233,261
     if (mk == RT_MAT_METAL) {                                               // hitPosition.h:230-239
-        V3 reflected = reflect(normalized(ray.d), rec.normal);
+        V3 reflected = reflect(unit_direction, rec.normal);
         float fuzz = sc.mat_fuzz[m];
         ray = make_ray(rec.p, reflected + fuzz * random_in_unit_sphere(g));
         w = rgb;
     } else if (mk == RT_MAT_DIELECTRIC) {                                   // hitPosition.h:253-287
-        double ir = sc.mat_ir[m];
-        double refraction_ratio = rec.front_face ? (1.0 / ir) : ir;
-        V3 unit_direction = normalized(ray.d);
+        double refraction_ratio = rec.front_face ? sc.mat_inv_ir[m] : sc.mat_ir[m];
         float cos_theta = float(__builtin_fmin(double(dot(-unit_direction, rec.normal)), 1.0));
         float sin_theta = float(__builtin_sqrt(double(1.0f - cos_theta * cos_theta)));
         bool cannot_refract = refraction_ratio * double(sin_theta) > 1.0;
@@ -315,16 +337,34 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const
         ray = make_ray(rec.p, direction);
         w = v3(1.0f, 1.0f, 1.0f);
     } else {                                                                // lambertian, hitPosition.h:202-216
-        Onb uvw;
-        uvw.build_from_w(rec.normal);                                       // cosine_pdf ctor, hitPosition.h:143
+        const V3 wn = normalized(rec.normal);                               // cosine_pdf's onb.w, hitPosition.h:143,129
+        const bool pick_light = g.u01() < 0.5f;                             // mixture_pdf::generate, hitPosition.cpp:67-72
         V3 dir;
-        if (g.u01() < 0.5f) dir = light_random(sc, g, rec.p);               // mixture_pdf::generate, hitPosition.cpp:67-72
-        else dir = uvw.local(random_cosine_direction(g));
+        if (sc.light_kind == RT_PRIM_SPHERE) {
+            // Both branches (sphere::random, shapes.h:129-135 + calc.h:75-86; cosine_pdf::generate,
+            // hitPosition.h:152-155 + calc.h:62-73) draw r1, r2, take sin/cos of 2*pi*r1, two square
+            // roots and an orthonormal basis: one copy of that code, operands selected per lane.
+            const float r1 = g.u01(), r2 = g.u01();
+            const V3 to_light = v3(sc.light_c[0], sc.light_c[1], sc.light_c[2]) - rec.p;
+            Onb sb;
+            sb.build_from_w(pick_light ? to_light : rec.normal);
+            const double radius = double(sc.light_r), distance_squared = double(length_squared(to_light));
+            const double s1 = __builtin_sqrt(pick_light ? 1 - radius * radius / distance_squared : double(1 - r2));
+            const double z = pick_light ? 1 + r2 * (s1 - 1) : s1;
+            const double s2 = __builtin_sqrt(pick_light ? 1 - z * z : double(r2));
+            const double phi = 2 * kPi * r1;
+            double sn, cs;
+            sincos_portable(phi, &sn, &cs);
+            dir = sb.local(v3(float(cs * s2), float(sn * s2), float(z)));
+        } else {
+            if (pick_light) dir = light_random(sc, g, rec.p);
+            else { Onb uvw; uvw.build_from_w(rec.normal); dir = uvw.local(random_cosine_direction(g)); }
+        }
         V3 ndir = normalized(dir);
         float cosine_s = dot(rec.normal, ndir);                             // lambertian::scattering_pdf
-        double spdf = cosine_s < 0 ? 0.0 : double(cosine_s) / kPi;
-        float cosine_c = dot(ndir, uvw.w);                                  // cosine_pdf::value
-        double cval = (cosine_c <= 0) ? 0.0 : double(cosine_c) / kPi;
+        double spdf = cosine_s < 0 ? 0.0 : div_by_pi(cosine_s, rpi);
+        float cosine_c = dot(ndir, wn);                                     // cosine_pdf::value
+        double cval = (cosine_c <= 0) ? 0.0 : div_by_pi(cosine_c, rpi);
         double pval = 0.5 * light_pdf_value(sc, rec.p, dir) + 0.5 * cval;   // mixture_pdf::value
         ray = make_ray(rec.p, dir);
         w = rgb * float(spdf); pdf = float(pval);
@@ -362,10 +402,11 @@ __device__ __forceinline__ V3 trace_path(const DevScene& sc, Ray ray, Rng& g, in
     Stamps stp{};
 #endif
     int level = 0;
+    const Recip64 rpi = recip64(kPi);
     V3 L = v3(0.0f, 0.0f, 0.0f);
     for (int depth_left = depth; depth_left > 0; --depth_left) {            // depth_left <= 0: black, calc.cpp:96-97
         Hit h = closest_hit(sc, ray, double(0.001f), kInf, words RT_STAMP_ARG);   // calc.cpp:99
-        if (shade_bounce(sc, ray, h, g, normals, st, level, L)) break;
+        if (shade_bounce(sc, ray, h, g, normals, st, level, rpi, L)) break;
         ++level;
         L = v3(0.0f, 0.0f, 0.0f);
     }
@@ -406,6 +447,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, DevCamera c
     PathStack st; st.base = ra.stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
     const bool normals = (ra.flags & RT_RENDER_NORMALS) != 0;
     const int spp_end = ra.spp_begin + ra.spp_count;
+    const Recip64 rpi = recip64(kPi);
 
     bool have = false, path = false;
     int x = 0, y = 0, s = 0, level = 0, depth_left = 0;
@@ -470,7 +512,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, DevCamera c
                 if (h2.prim != h.prim || __double_as_longlong(h2.t) != __double_as_longlong(h.t)) atomicAdd(ra.mismatches, 1ull);
             }
             V3 L;
-            bool done = shade_bounce(sc, ray, h, g, normals, st, level, L);
+            bool done = shade_bounce(sc, ray, h, g, normals, st, level, rpi, L);
             if (!done) {
                 ++level; --depth_left;
                 if (depth_left <= 0) { L = v3(0.0f, 0.0f, 0.0f); done = true; }   // calc.cpp:96-97
@@ -843,8 +885,10 @@ int rt_upload_scene(const RtScene* s) {
         return 1;
     std::vector<int> mk(s->mat_kind, s->mat_kind + s->n_mats);
     std::vector<float> mrgb(s->mat_rgb, s->mat_rgb + 3 * size_t(s->n_mats)), mf(s->mat_fuzz, s->mat_fuzz + s->n_mats);
-    std::vector<double> mir(s->mat_ir, s->mat_ir + s->n_mats);
-    if (upload(mk, &ds.mat_kind) || upload(mrgb, &ds.mat_rgb) || upload(mf, &ds.mat_fuzz) || upload(mir, &ds.mat_ir)) return 1;
+    std::vector<double> mir(s->mat_ir, s->mat_ir + s->n_mats), minv(s->n_mats);
+    for (int i = 0; i < s->n_mats; ++i) minv[i] = 1.0 / mir[i];
+    if (upload(mk, &ds.mat_kind) || upload(mrgb, &ds.mat_rgb) || upload(mf, &ds.mat_fuzz) || upload(mir, &ds.mat_ir) ||
+        upload(minv, &ds.mat_inv_ir)) return 1;
     if (upload(fx, &sg.fx) || upload(fy, &sg.fy) || upload(fz, &sg.fz) || upload(fk, &sg.fk) || upload(fq, &sg.fq)) return 1;
     ds.sg = sg;
     ds.light_kind = s->light_kind;
