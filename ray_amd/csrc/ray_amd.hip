@@ -160,10 +160,10 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
     Hit h; h.t = t_max; h.prim = -1;
     bool ok = sc.sg.fast_ok && ray_in_fast_range(r.o, r.d, r.dl2) && t_min == t_min && t_max == t_max;
     if (ok) {
-        HitState hs; hs.bt = t_max; hs.bi = -1; hs.btf = __double2float_ru(t_max);
-        const float tminf = __double2float_rd(t_min);
-        scan_spheres(sc.sg, sc.sph, sc.sph_prim, r.o, r.d, r.dl2, t_min, tminf, hs, words RT_STAMP_ARG);
-        h.t = hs.bt; h.prim = hs.bi;
+        HitState hs;
+        hit_state_init(hs, t_max);
+        scan_spheres(sc.sg, sc.sph_prim, r.o, r.d, r.dl2, t_min, t_max, hs, words RT_STAMP_ARG);
+        h.t = hs.bt; h.prim = hs.idx;
         bool saw_nan = false;
         for (int j = 0; j < sc.n_rect; ++j) {
             double t;
@@ -438,7 +438,7 @@ struct RenderArgs {
 // A lane whose pixel is finished takes the next pixel of the wave's tile queue; an empty queue is
 // refilled with one 8x8 tile from a global counter (one atomic per wave and tile).
 template <bool VERIFY>
-__global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra) {
+__global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra) {
     __shared__ uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -847,9 +847,15 @@ int rt_upload_scene(const RtScene* s) {
                 std::fill(in_filter.begin(), in_filter.end(), 0); n_filter = 0;
             }
         }
+        // slot layout: exact group in pairs, padded to whole 32-pair words; then the filter group in pairs,
+        // padded to a multiple of 8 pairs. Pads: NaN centre (never a candidate), prim -1, k = 3e38.
+        const float nanf_ = std::numeric_limits<float>::quiet_NaN();
+        const float4 pad = make_float4(nanf_, nanf_, nanf_, 1.0f);
         std::vector<float4> sph2; std::vector<int> prim2;
         for (int i = 0; i < n; ++i) if (!in_filter[i]) { prim_local[sph_prim[i]] = int(sph2.size()); sph2.push_back(sph[i]); prim2.push_back(sph_prim[i]); }
-        sg.n_exact = int(sph2.size());
+        sg.n_epairs = int((sph2.size() + 1) / 2);
+        sg.n_ewords = (sg.n_epairs + 31) / 32;
+        while (int(sph2.size()) < sg.n_ewords * 64) { sph2.push_back(pad); prim2.push_back(-1); }
         double cmax = 0, r2max = 0;
         for (int i = 0; i < n; ++i) if (in_filter[i]) {
             prim_local[sph_prim[i]] = int(sph2.size()); sph2.push_back(sph[i]); prim2.push_back(sph_prim[i]);
@@ -859,14 +865,13 @@ int rt_upload_scene(const RtScene* s) {
             fx.push_back(rx); fy.push_back(ry); fz.push_back(rz); fk.push_back(float(c2 - double(r2)));
             cmax = std::max(cmax, std::sqrt(c2)); r2max = std::max(r2max, double(r2));
         }
-        const float nanf_ = std::numeric_limits<float>::quiet_NaN();
-        while (fx.size() % 16 != 0) {   // pads: never flagged (k huge), never a candidate (NaN centre)
+        while (fx.size() % 16 != 0) {
             fx.push_back(0.0f); fy.push_back(0.0f); fz.push_back(0.0f); fk.push_back(3.0e38f);
-            sph2.push_back(make_float4(nanf_, nanf_, nanf_, 1.0f)); prim2.push_back(-1);
+            sph2.push_back(pad); prim2.push_back(-1);
         }
         sg.n_fpairs = int(fx.size() / 2);
-        for (int pr = 0; pr < sg.n_fpairs; ++pr) {
-            const float4 s0 = sph2[sg.n_exact + 2 * pr], s1 = sph2[sg.n_exact + 2 * pr + 1];
+        for (size_t pr = 0; pr < sph2.size() / 2; ++pr) {
+            const float4 s0 = sph2[2 * pr], s1 = sph2[2 * pr + 1];
             fq.push_back(make_float4(s0.x, s1.x, s0.y, s1.y));
             fq.push_back(make_float4(s0.z, s1.z, s0.w * s0.w, s1.w * s1.w));
         }
