@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "../include/ray_amd.h"
+#include "../include/ray_amd_tri.h"
 
 #if defined(__FMA__)
 #error "build the oracle without -mfma / -march=native: the reference arithmetic has no FMA contraction"
@@ -386,11 +387,19 @@ struct Rect : Shape {
 };
 
 // Not in the reference (BASELINE.json configs[3]): Moeller-Trumbore in FP32 with separately
-// rounded operations, build-defined; "parity unpinned". e1, e2 and the unit normal are derived
-// once per triangle. Comparisons are written so that NaN means miss.
+// rounded operations plus containment of the hit point in the triangle's bounding sphere
+// (include/ray_amd_tri.h), build-defined; "parity unpinned". e1, e2, the unit normal and the
+// bounding sphere are derived once per triangle. Comparisons are written so that NaN means miss.
 struct Triangle : Shape {
-    V3 v0, e1, e2, n;
-    Triangle(V3 a, V3 b, V3 c) : v0(a), e1(b - a), e2(c - a) { n = cross(e1, e2).normalized(); }
+    V3 v0, e1, e2, n, cb;
+    float rb2;
+    Triangle(V3 a, V3 b, V3 c) : v0(a), e1(b - a), e2(c - a) {
+        n = cross(e1, e2).normalized();
+        const float fa[3] = {a.x, a.y, a.z}, fb[3] = {b.x, b.y, b.z}, fc[3] = {c.x, c.y, c.z};
+        float ctr[3];
+        rt_triangle_bound(fa, fb, fc, ctr, &rb2);
+        cb = V3(ctr[0], ctr[1], ctr[2]);
+    }
     std::optional<HitRecord> hit(const Ray& r, double t_min, double t_max) const override {
         V3 pvec = cross(r.d, e2);
         float det = dot(e1, pvec);
@@ -403,6 +412,8 @@ struct Triangle : Shape {
         float v = dot(r.d, qvec) * inv;
         if (!(v >= 0.0f && u + v <= 1.0f)) return {};
         double t = double(dot(e2, qvec) * inv);
+        V3 dp = r.at(t) - cb;
+        if (!(dp.lengthSquared() <= rb2)) return {};
         if (!(t >= t_min && t <= t_max)) return {};
         HitRecord rec;
         rec.t = t; rec.u = u; rec.v = v; rec.mat = mat; rec.prim = prim;

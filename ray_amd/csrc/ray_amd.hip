@@ -10,12 +10,14 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
 #include <vector>
 
 #include "../../include/ray_amd.h"
+#include "../../include/ray_amd_tri.h"
 #include "rt_device.hpp"
 #include "rt_scan.hpp"
 
@@ -31,7 +33,7 @@ struct DevScene {
     const double* __restrict__ rect;       // [n_rect][5] (a0, a1, b0, b1, k)
     const int* __restrict__ rect_axis;     // [n_rect] 0 = XY (z = k), 1 = XZ (y = k), 2 = YZ (x = k)
     const int* __restrict__ rect_prim;     // [n_rect]
-    const float* __restrict__ tri;         // [n_tri][12] v0, e1, e2, unit normal
+    const float* __restrict__ tri;         // [n_tri][16] v0, e1, e2, unit normal, bounding sphere centre, radius^2 (ray_amd_tri.h)
     const int* __restrict__ tri_prim;      // [n_tri]
     const int* __restrict__ prim_kind;     // [n_prims] 0 sphere, 1 rect, 2 triangle (device kinds)
     const int* __restrict__ prim_local;    // [n_prims] index inside its kind's arrays
@@ -45,7 +47,8 @@ struct DevScene {
     float light_c[3], light_r;             // sphere light
     double light_rect[5];                  // rect light
     float bg[3];
-    SphereGroups sg;                       // exact / filter partition of the sphere arrays (rt_scan.hpp)
+    FilterGroup sg, tg;                    // exact / filter partition of the sphere and triangle slots (rt_scan.hpp)
+    int fast_ok;                           // 0: a primitive is non-finite / out of range -> list-order scan only
 };
 
 struct DevCamera {
@@ -126,6 +129,8 @@ RT_DEV bool tri_t(const Ray& r, const float* __restrict__ q, double t_min, doubl
     float v = dot(r.d, qvec) * inv;
     if (!(v >= 0.0f && u + v <= 1.0f)) return false;
     double t = double(dot(e2, qvec) * inv);
+    V3 dp = ray_at(r, t) - v3(q[12], q[13], q[14]);   // hit point inside the bounding sphere (ray_amd_tri.h)
+    if (!(length_squared(dp) <= q[15])) return false;
     if (!(t >= t_min && t <= bt) || (t == bt && idx < bi)) return false;
     *t_out = t;
     return true;
@@ -147,10 +152,35 @@ __device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const R
         double t; bool ok;
         if (k == 0) ok = sphere_t(r, sc.sph[j], t_min, h.t, i, h.prim, &t);
         else if (k == 1) ok = rect_t(r, sc.rect_axis[j], sc.rect + 5 * j, t_min, h.t, i, h.prim, &t);
-        else ok = tri_t(r, sc.tri + 12 * j, t_min, h.t, i, h.prim, &t);
+        else ok = tri_t(r, sc.tri + 16 * j, t_min, h.t, i, h.prim, &t);
         if (ok) { h.t = t; h.prim = i; }
     }
     return h;
+}
+
+// Triangles of one ray: the sphere filter of rt_scan.hpp on the triangles' bounding spheres (every hit
+// point lies inside its triangle's sphere by definition of the primitive, ray_amd_tri.h), then
+// tri_t on the flagged pairs. h is exact on entry and on return.
+__device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r, double t_min, Hit& h, uint32_t* words RT_STAMP_PARAM) {
+    const FilterGroup& tg = sc.tg;
+    const int n_words = group_words(tg);
+    if (n_words == 0) return;
+    const FilterRay fr = filter_ray(tg, r.o, r.d, r.dl2, __builtin_amdgcn_rcpf(r.dl2));
+    for (int w0 = 0; w0 < n_words; w0 += kMaskWords) {
+        const int nw = n_words - w0 < kMaskWords ? n_words - w0 : kMaskWords;
+        const uint32_t summary = filter_words(tg, fr, w0, nw, words);
+        RT_STAMP(2);
+        walk_flagged(summary, w0, words, [&](int pair) {
+#pragma unroll 1
+            for (int hh = 0; hh < 2; ++hh) {
+                const int slot = 2 * pair + hh;
+                const int idx = sc.tri_prim[slot];
+                double t;
+                if (tri_t(r, sc.tri + 16 * slot, t_min, h.t, idx, h.prim, &t)) { h.t = t; h.prim = idx; }
+            }
+        } RT_STAMP_ARG);
+        RT_STAMP(3);
+    }
 }
 
 // Fast scan: spheres through rt_scan.hpp (filter + exact), then rects and triangles. Lanes whose ray
@@ -158,7 +188,7 @@ __device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const R
 // rect, fall back to the list-order scan, which is the reference loop itself.
 __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, double t_min, double t_max, uint32_t* words RT_STAMP_PARAM) {
     Hit h; h.t = t_max; h.prim = -1;
-    bool ok = sc.sg.fast_ok && ray_in_fast_range(r.o, r.d, r.dl2) && t_min == t_min && t_max == t_max;
+    bool ok = sc.fast_ok && ray_in_fast_range(r.o, r.d, r.dl2) && t_min == t_min && t_max == t_max;
     if (ok) {
         HitState hs;
         hit_state_init(hs, t_max);
@@ -172,11 +202,7 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
                 if (t != t) saw_nan = true; else { h.t = t; h.prim = idx; }
             }
         }
-        for (int j = 0; j < sc.n_tri; ++j) {
-            double t;
-            int idx = sc.tri_prim[j];
-            if (tri_t(r, sc.tri + 12 * j, t_min, h.t, idx, h.prim, &t)) { h.t = t; h.prim = idx; }
-        }
+        if (!saw_nan) scan_triangles(sc, r, t_min, h, words RT_STAMP_ARG);
         ok = !saw_nan;
     }
     if (!ok) h = closest_hit_listorder(sc, r, t_min, t_max);
@@ -201,7 +227,7 @@ __device__ __forceinline__ HitRec hit_record(const DevScene& sc, const Ray& r, c
         int axis = sc.rect_axis[j];
         outward = axis == 0 ? v3(0, 0, 1) : (axis == 1 ? v3(0, 1, 0) : v3(1, 0, 0));
     } else {
-        const float* q = sc.tri + 12 * j;
+        const float* q = sc.tri + 16 * j;
         outward = v3(q[9], q[10], q[11]);
     }
     rec.front_face = dot(r.d, outward) < 0.0f;
@@ -697,6 +723,62 @@ void free_scene() {
     g.have_scene = false;
 }
 
+// Partition of one kind's items (bounding spheres: centre xyz + radius w; r2k: the radius^2 the filter
+// uses) into the exact group and the filter group of rt_scan.hpp, and the slot order of the arrays:
+// exact group in pairs, padded to whole 32-pair words; then the filter group in pairs, padded to a
+// multiple of 8 pairs. slot_item[slot] = item index, or -1 for a pad.
+struct GroupBuild {
+    FilterGroup fg{};
+    std::vector<int> slot_item;
+    std::vector<float> fx, fy, fz, fk;
+};
+void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k, float margin_k, bool finite, GroupBuild& out) {
+    const int n = int(bound.size());
+    std::vector<char> in_filter(n, 0);
+    double gc[3] = {0, 0, 0};
+    if (finite && n >= 16) {
+        std::vector<double> tmp(n);
+        for (int k = 0; k < 3; ++k) {
+            for (int i = 0; i < n; ++i) tmp[i] = k == 0 ? bound[i].x : (k == 1 ? bound[i].y : bound[i].z);
+            std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
+            gc[k] = double(float(tmp[n / 2]));
+        }
+        std::vector<double> ext(n);
+        for (int i = 0; i < n; ++i) {
+            double dx = bound[i].x - gc[0], dy = bound[i].y - gc[1], dz = bound[i].z - gc[2];
+            ext[i] = std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs(double(bound[i].w));
+        }
+        tmp = ext;
+        std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
+        const double thr = std::min(8.0 * tmp[n / 2], 0.5e6);
+        int n_filter = 0;
+        for (int i = 0; i < n; ++i) if (ext[i] <= thr) { in_filter[i] = 1; ++n_filter; }
+        if (n_filter < 16 || std::fabs(gc[0]) > 0.5e6 || std::fabs(gc[1]) > 0.5e6 || std::fabs(gc[2]) > 0.5e6)
+            std::fill(in_filter.begin(), in_filter.end(), 0);
+    }
+    FilterGroup& fg = out.fg;
+    for (int i = 0; i < n; ++i) if (!in_filter[i]) out.slot_item.push_back(i);
+    fg.n_epairs = int((out.slot_item.size() + 1) / 2);
+    fg.n_ewords = (fg.n_epairs + 31) / 32;
+    out.slot_item.resize(size_t(fg.n_ewords) * 64, -1);
+    double cmax = 0, r2max = 0;
+    for (int i = 0; i < n; ++i) if (in_filter[i]) {
+        out.slot_item.push_back(i);
+        const float rx = float(bound[i].x - gc[0]), ry = float(bound[i].y - gc[1]), rz = float(bound[i].z - gc[2]);
+        const double c2 = double(rx) * rx + double(ry) * ry + double(rz) * rz;
+        out.fx.push_back(rx); out.fy.push_back(ry); out.fz.push_back(rz); out.fk.push_back(float(c2 - double(r2k[i])));
+        cmax = std::max(cmax, std::sqrt(c2)); r2max = std::max(r2max, double(r2k[i]));
+    }
+    while (out.fx.size() % 16 != 0) {   // pads: k huge, never flagged
+        out.fx.push_back(0.0f); out.fy.push_back(0.0f); out.fz.push_back(0.0f); out.fk.push_back(3.0e38f);
+        out.slot_item.push_back(-1);
+    }
+    fg.n_fpairs = int(out.fx.size() / 2);
+    fg.gx = float(gc[0]); fg.gy = float(gc[1]); fg.gz = float(gc[2]);
+    fg.cmax = float(cmax * 1.000001) + 1.0e-30f; fg.r2max = float(r2max * 1.000001);
+    fg.margin_k = margin_k;
+}
+
 int grid_for(int n_tiles) {
     int resident = g.prop.multiProcessorCount * 8;   // 8 blocks of 256 threads per CU = 32 waves/CU
     return n_tiles < resident ? (n_tiles > 0 ? n_tiles : 1) : resident;
@@ -801,8 +883,11 @@ int rt_upload_scene(const RtScene* s) {
             V3 v0 = v3(float(d[0]), float(d[1]), float(d[2])), v1 = v3(float(d[3]), float(d[4]), float(d[5])),
                v2 = v3(float(d[6]), float(d[7]), float(d[8]));
             V3 e1 = v1 - v0, e2 = v2 - v0, nn = normalized(cross(e1, e2));
-            const float q[12] = {v0.x, v0.y, v0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z, nn.x, nn.y, nn.z};
-            tri.insert(tri.end(), q, q + 12); tri_prim.push_back(i);
+            const float fa[3] = {v0.x, v0.y, v0.z}, fb[3] = {v1.x, v1.y, v1.z}, fc[3] = {v2.x, v2.y, v2.z};
+            float cb[3], rb2;
+            rt_triangle_bound(fa, fb, fc, cb, &rb2);
+            const float q[16] = {v0.x, v0.y, v0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z, nn.x, nn.y, nn.z, cb[0], cb[1], cb[2], rb2};
+            tri.insert(tri.end(), q, q + 16); tri_prim.push_back(i);
             break; }
         default: return fail("rt_upload_scene: primitive %d has unknown kind %d", i, s->prim_kind[i]);
         }
@@ -814,70 +899,53 @@ int rt_upload_scene(const RtScene* s) {
         s->light_kind != RT_PRIM_XZ_RECT)
         return fail("rt_upload_scene: light kind %d has no pdf_value/random in the reference; pass RT_LIGHT_BASE", s->light_kind);
 
-    // ---- sphere groups (rt_scan.hpp): exact group first, then the filter group in pairs, padded ---------
-    SphereGroups sg{};
-    std::vector<float> fx, fy, fz, fk;
+    // ---- filter groups (rt_scan.hpp) of the spheres and of the triangles' bounding spheres ------------------
+    bool finite = true;
+    GroupBuild sgb, tgb;
     std::vector<float4> fq;
     {
-        const int n = int(sph.size());
-        bool finite = true;
-        for (const float4& q : sph)
-            if (!(std::fabs(q.x) <= 1.0e7f && std::fabs(q.y) <= 1.0e7f && std::fabs(q.z) <= 1.0e7f && std::fabs(q.w) <= 1.0e7f)) finite = false;
-        sg.fast_ok = finite ? 1 : 0;
-        std::vector<char> in_filter(n, 0);
-        double gc[3] = {0, 0, 0};
-        int n_filter = 0;
-        if (finite && n >= 16) {
-            std::vector<double> tmp(n);
-            for (int k = 0; k < 3; ++k) {
-                for (int i = 0; i < n; ++i) tmp[i] = k == 0 ? sph[i].x : (k == 1 ? sph[i].y : sph[i].z);
-                std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
-                gc[k] = double(float(tmp[n / 2]));
-            }
-            std::vector<double> ext(n);
-            for (int i = 0; i < n; ++i) {
-                double dx = sph[i].x - gc[0], dy = sph[i].y - gc[1], dz = sph[i].z - gc[2];
-                ext[i] = std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs(double(sph[i].w));
-            }
-            tmp = ext;
-            std::nth_element(tmp.begin(), tmp.begin() + n / 2, tmp.end());
-            const double thr = std::min(8.0 * tmp[n / 2], 0.5e6);
-            for (int i = 0; i < n; ++i) if (ext[i] <= thr) { in_filter[i] = 1; ++n_filter; }
-            if (n_filter < 16 || std::fabs(gc[0]) > 0.5e6 || std::fabs(gc[1]) > 0.5e6 || std::fabs(gc[2]) > 0.5e6) {
-                std::fill(in_filter.begin(), in_filter.end(), 0); n_filter = 0;
-            }
+        std::vector<float4> bound(sph.size());
+        std::vector<float> r2k(sph.size());
+        for (size_t i = 0; i < sph.size(); ++i) {
+            bound[i] = sph[i]; r2k[i] = sph[i].w * sph[i].w;   // radiusSquared, shapes.h:73
+            if (!(std::fabs(sph[i].x) <= 1.0e7f && std::fabs(sph[i].y) <= 1.0e7f && std::fabs(sph[i].z) <= 1.0e7f && std::fabs(sph[i].w) <= 1.0e7f)) finite = false;
         }
-        // slot layout: exact group in pairs, padded to whole 32-pair words; then the filter group in pairs,
-        // padded to a multiple of 8 pairs. Pads: NaN centre (never a candidate), prim -1, k = 3e38.
+        build_group(bound, r2k, kMarginK, finite, sgb);
         const float nanf_ = std::numeric_limits<float>::quiet_NaN();
-        const float4 pad = make_float4(nanf_, nanf_, nanf_, 1.0f);
-        std::vector<float4> sph2; std::vector<int> prim2;
-        for (int i = 0; i < n; ++i) if (!in_filter[i]) { prim_local[sph_prim[i]] = int(sph2.size()); sph2.push_back(sph[i]); prim2.push_back(sph_prim[i]); }
-        sg.n_epairs = int((sph2.size() + 1) / 2);
-        sg.n_ewords = (sg.n_epairs + 31) / 32;
-        while (int(sph2.size()) < sg.n_ewords * 64) { sph2.push_back(pad); prim2.push_back(-1); }
-        double cmax = 0, r2max = 0;
-        for (int i = 0; i < n; ++i) if (in_filter[i]) {
-            prim_local[sph_prim[i]] = int(sph2.size()); sph2.push_back(sph[i]); prim2.push_back(sph_prim[i]);
-            const float rx = float(sph[i].x - gc[0]), ry = float(sph[i].y - gc[1]), rz = float(sph[i].z - gc[2]);
-            const float r2 = sph[i].w * sph[i].w;   // radiusSquared, shapes.h:73
-            const double c2 = double(rx) * rx + double(ry) * ry + double(rz) * rz;
-            fx.push_back(rx); fy.push_back(ry); fz.push_back(rz); fk.push_back(float(c2 - double(r2)));
-            cmax = std::max(cmax, std::sqrt(c2)); r2max = std::max(r2max, double(r2));
+        std::vector<float4> sph2(sgb.slot_item.size(), make_float4(nanf_, nanf_, nanf_, 1.0f));
+        std::vector<int> prim2(sgb.slot_item.size(), -1);
+        for (size_t sl = 0; sl < sgb.slot_item.size(); ++sl) {
+            const int it = sgb.slot_item[sl];
+            if (it >= 0) { sph2[sl] = sph[it]; prim2[sl] = sph_prim[it]; prim_local[sph_prim[it]] = int(sl); }
         }
-        while (fx.size() % 16 != 0) {
-            fx.push_back(0.0f); fy.push_back(0.0f); fz.push_back(0.0f); fk.push_back(3.0e38f);
-            sph2.push_back(pad); prim2.push_back(-1);
-        }
-        sg.n_fpairs = int(fx.size() / 2);
         for (size_t pr = 0; pr < sph2.size() / 2; ++pr) {
             const float4 s0 = sph2[2 * pr], s1 = sph2[2 * pr + 1];
             fq.push_back(make_float4(s0.x, s1.x, s0.y, s1.y));
             fq.push_back(make_float4(s0.z, s1.z, s0.w * s0.w, s1.w * s1.w));
         }
-        sg.gx = float(gc[0]); sg.gy = float(gc[1]); sg.gz = float(gc[2]);
-        sg.cmax = float(cmax * 1.000001) + 1.0e-30f; sg.r2max = float(r2max * 1.000001);
         sph.swap(sph2); sph_prim.swap(prim2);
+    }
+    {
+        const size_t nt = tri_prim.size();
+        std::vector<float4> bound(nt);
+        std::vector<float> r2k(nt);
+        for (size_t i = 0; i < nt; ++i) {
+            const float* q = &tri[16 * i];
+            const float rb = std::sqrt(q[15]);
+            bound[i] = make_float4(q[12], q[13], q[14], rb);
+            r2k[i] = q[15] * 1.0001f;   // the FP32 containment test of tri_t passes only inside this sphere
+            for (int k = 0; k < 9; ++k) if (!(std::fabs(q[k]) <= 1.0e7f)) finite = false;
+            if (!(rb <= 1.0e7f)) finite = false;
+        }
+        build_group(bound, r2k, kMarginKTri, finite, tgb);
+        const float nanf_ = std::numeric_limits<float>::quiet_NaN();
+        std::vector<float> tri2(tgb.slot_item.size() * 16, nanf_);
+        std::vector<int> prim2(tgb.slot_item.size(), -1);
+        for (size_t sl = 0; sl < tgb.slot_item.size(); ++sl) {
+            const int it = tgb.slot_item[sl];
+            if (it >= 0) { std::copy(&tri[16 * it], &tri[16 * it] + 16, &tri2[16 * sl]); prim2[sl] = tri_prim[it]; prim_local[tri_prim[it]] = int(sl); }
+        }
+        tri.swap(tri2); tri_prim.swap(prim2);
     }
 
     HIP_OK(hipStreamSynchronize(g.stream));
@@ -894,8 +962,11 @@ int rt_upload_scene(const RtScene* s) {
     for (int i = 0; i < s->n_mats; ++i) minv[i] = 1.0 / mir[i];
     if (upload(mk, &ds.mat_kind) || upload(mrgb, &ds.mat_rgb) || upload(mf, &ds.mat_fuzz) || upload(mir, &ds.mat_ir) ||
         upload(minv, &ds.mat_inv_ir)) return 1;
-    if (upload(fx, &sg.fx) || upload(fy, &sg.fy) || upload(fz, &sg.fz) || upload(fk, &sg.fk) || upload(fq, &sg.fq)) return 1;
-    ds.sg = sg;
+    if (upload(sgb.fx, &sgb.fg.fx) || upload(sgb.fy, &sgb.fg.fy) || upload(sgb.fz, &sgb.fg.fz) || upload(sgb.fk, &sgb.fg.fk) ||
+        upload(fq, &sgb.fg.fq)) return 1;
+    if (upload(tgb.fx, &tgb.fg.fx) || upload(tgb.fy, &tgb.fg.fy) || upload(tgb.fz, &tgb.fg.fz) || upload(tgb.fk, &tgb.fg.fk)) return 1;
+    tgb.fg.fq = nullptr;
+    ds.sg = sgb.fg; ds.tg = tgb.fg; ds.fast_ok = finite ? 1 : 0;
     ds.light_kind = s->light_kind;
     for (int k = 0; k < 3; ++k) ds.light_c[k] = float(s->light_data[k]);
     ds.light_r = float(s->light_data[3]);
@@ -1020,7 +1091,10 @@ int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_cou
         return finish_timed(1);
     }
     const int n_tiles = ((w + kTile - 1) / kTile) * ((y_count + kTile - 1) / kTile);   // one 8x8 tile per wave at a time
-    const int resident = g.prop.multiProcessorCount * g.render_blocks_per_cu;
+    int resident = g.prop.multiProcessorCount * g.render_blocks_per_cu;
+#ifdef RT_STAMPS
+    if (const char* e = getenv("RT_BPC")) resident = g.prop.multiProcessorCount * atoi(e);   // diagnostic: blocks per CU
+#endif
     const int want = (n_tiles + 3) / 4;
     const int grid = want < resident ? want : resident;
     if (ensure_stack(depth, grid)) return 1;

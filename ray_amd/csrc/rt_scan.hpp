@@ -32,21 +32,23 @@ constexpr float kMarginK = 96.0f * 5.9604644775390625e-08f;
 // a ray takes the fast path only inside these magnitudes (no overflow, no NaN in either level)
 constexpr float kMaxCoord = 1.0e6f, kMinA = 1.0e-12f, kMaxA = 3.0e12f;
 
+// One filter group (the spheres, or the triangles through their bounding spheres, ray_amd_tri.h).
 // Pair index space: words [0, n_ewords) hold the exact group (n_epairs real pairs, always flagged, the
 // rest of the last word unused), words from n_ewords on hold the filter group (n_fpairs pairs, a
-// multiple of 8). Sphere 2*pair + h of the sphere arrays (sph, sph_prim) belongs to pair `pair`.
-struct SphereGroups {
+// multiple of 8). Item slot 2*pair + h of the kind's arrays belongs to pair `pair`.
+struct FilterGroup {
     int n_epairs, n_ewords;
     int n_fpairs;
     const float* __restrict__ fx;    // [2 n_fpairs] centre - g, filter group only          (pads: 0)
     const float* __restrict__ fy;
     const float* __restrict__ fz;
     const float* __restrict__ fk;    // [2 n_fpairs] |centre - g|^2 - r^2                   (pads: 3e38)
-    const float4* __restrict__ fq;   // [2 * all pairs] per pair (cx0,cx1,cy0,cy1), (cz0,cz1,r2_0,r2_1); pads NaN
+    const float4* __restrict__ fq;   // spheres only: [2 * all pairs] per pair (cx0,cx1,cy0,cy1), (cz0,cz1,r2_0,r2_1); pads NaN
     float gx, gy, gz;                // reference point of the filter group
     float cmax, r2max;               // max |centre - g| (rounded up), max r^2 over the filter group
-    int fast_ok;                     // 0: some sphere is non-finite / out of range -> list-order scan only
+    float margin_k;                  // M = margin_k * a * (S^2 + So^2 + r2max)
 };
+constexpr float kMarginKTri = 160.0f * 5.9604644775390625e-08f;   // + the FP32 hit point's rounding (ray_amd_tri.h)
 
 // Diagnostic build only (-DRT_STAMPS): cycles per section of the render loop (s_memtime, wave-uniform)
 // and wave-level pass counts of the divergent loops. Never compiled into the product library.
@@ -146,86 +148,108 @@ RT_DEV bool ray_in_fast_range(V3 o, V3 d, float a) {
            a >= kMinA && a <= kMaxA;
 }
 
-// Spheres of one ray (o, d, a = d.lengthSquared() as Ray.h:8 caches it). `words` is this thread's
-// column of the block's flag-word array in LDS (stride kScanBlock). sph_prim: flattened primitive
-// index per sphere slot (-1 for pads). Requires ray_in_fast_range and sg.fast_ok. On return h is exact.
-__device__ __forceinline__ void scan_spheres(const SphereGroups& sg, const int* __restrict__ sph_prim, V3 o, V3 d, float a, double t_min,
-                                             double t_max, HitState& h, uint32_t* words RT_STAMP_PARAM) {
-    const int n_fbatches = sg.n_fpairs >> 3;                  // 8 pairs each
-    const int n_words = sg.n_ewords + ((n_fbatches + 3) >> 2);
-    if (n_words == 0) return;
-    const float tmin_lo = __double2float_rd(t_min), tmin_hi = __double2float_ru(t_min);
-    // ---- filter constants of this ray -----------------------------------------------------------------
-    V3 orel = o - v3(sg.gx, sg.gy, sg.gz);
-    float ia = __builtin_amdgcn_rcpf(a);
+// Filter constants of one ray for one group (DESIGN.md "sphere filter").
+struct FilterRay {
+    f2 DX, DY, DZ, OD, MM, NA, WX, WY, WZ;
+};
+__device__ __forceinline__ FilterRay filter_ray(const FilterGroup& fg, V3 o, V3 d, float a, float ia) {
+    V3 orel = o - v3(fg.gx, fg.gy, fg.gz);
     float s = -(orel.x * d.x + orel.y * d.y + orel.z * d.z) * ia;
     V3 op = v3(__builtin_fmaf(s, d.x, orel.x), __builtin_fmaf(s, d.y, orel.y), __builtin_fmaf(s, d.z, orel.z));   // a point of the line near g
     float od = __builtin_fmaf(op.z, d.z, __builtin_fmaf(op.y, d.y, op.x * d.x));
     float oo = __builtin_fmaf(op.z, op.z, __builtin_fmaf(op.y, op.y, op.x * op.x));
-    float S = __builtin_amdgcn_sqrtf(oo) * 1.001f + sg.cmax;
-    float So = __builtin_amdgcn_sqrtf(length_squared(orel)) * 1.001f + sg.cmax;
-    float M = kMarginK * a * (S * S + So * So + sg.r2max);
+    float S = __builtin_amdgcn_sqrtf(oo) * 1.001f + fg.cmax;
+    float So = __builtin_amdgcn_sqrtf(length_squared(orel)) * 1.001f + fg.cmax;
+    float M = fg.margin_k * a * (S * S + So * So + fg.r2max);
     float m2 = M - a * oo, wa = 2.0f * a;
-    const f2 DX = {d.x, d.x}, DY = {d.y, d.y}, DZ = {d.z, d.z}, OD = {od, od}, MM = {m2, m2}, NA = {-a, -a};
-    const f2 WX = {wa * op.x, wa * op.x}, WY = {wa * op.y, wa * op.y}, WZ = {wa * op.z, wa * op.z};
-    const f2 OX = {o.x, o.x}, OY = {o.y, o.y}, OZ = {o.z, o.z}, AA = {a, a};
-    cf2p fx = RT_CONST_F2(sg.fx), fy = RT_CONST_F2(sg.fy), fz = RT_CONST_F2(sg.fz), fk = RT_CONST_F2(sg.fk);
+    FilterRay fr;
+    fr.DX = f2{d.x, d.x}; fr.DY = f2{d.y, d.y}; fr.DZ = f2{d.z, d.z}; fr.OD = f2{od, od}; fr.MM = f2{m2, m2}; fr.NA = f2{-a, -a};
+    fr.WX = f2{wa * op.x, wa * op.x}; fr.WY = f2{wa * op.y, wa * op.y}; fr.WZ = f2{wa * op.z, wa * op.z};
+    return fr;
+}
 
+// Level 1 for words [w0, w0 + nw) of a group: one flag bit per pair (pair p of a word <-> bit 31 - p),
+// words to this thread's LDS column; returns the mask of non-empty words.
+__device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const FilterRay& fr, int w0, int nw, uint32_t* words) {
+    cf2p fx = RT_CONST_F2(fg.fx), fy = RT_CONST_F2(fg.fy), fz = RT_CONST_F2(fg.fz), fk = RT_CONST_F2(fg.fk);
+    const int n_fbatches = fg.n_fpairs >> 3;                  // 8 pairs each
+    uint32_t summary = 0;
+    for (int wi = 0; wi < nw; ++wi) {
+        const int gw = w0 + wi;
+        uint32_t flagged;
+        if (gw < fg.n_ewords) {                                // exact group: every real pair
+            const int real = fg.n_epairs - gw * 32;
+            flagged = real >= 32 ? 0xffffffffu : ~(0xffffffffu >> real);
+        } else {
+            int batch = (gw - fg.n_ewords) * 4;
+            const int nb = n_fbatches - batch < 4 ? n_fbatches - batch : 4;
+            uint32_t m = 0;
+            for (int bb = 0; bb < nb; ++bb, ++batch) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int j = batch * 8 + jj;
+                    f2 X = fx[j], Y = fy[j], Z = fz[j], K = fk[j];
+                    f2 bq = __builtin_elementwise_fma(-Z, fr.DZ, __builtin_elementwise_fma(-Y, fr.DY, __builtin_elementwise_fma(-X, fr.DX, fr.OD)));
+                    f2 Q = __builtin_elementwise_fma(fr.NA, K, fr.MM);
+                    Q = __builtin_elementwise_fma(fr.WX, X, Q);
+                    Q = __builtin_elementwise_fma(fr.WY, Y, Q);
+                    Q = __builtin_elementwise_fma(fr.WZ, Z, Q);
+                    f2 T = __builtin_elementwise_fma(bq, bq, Q);   // >= 0 (sign bit clear): flagged
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x) & __float_as_uint(T.y), 31);
+                }
+            }
+            if (nb < 4) m = (m << (32 - 8 * nb)) | (0xffffffffu >> (8 * nb));
+            flagged = ~m;
+        }
+        words[wi * kScanBlock] = flagged;
+        summary |= (flagged != 0u ? 1u : 0u) << wi;
+    }
+    return summary;
+}
+
+// Level 2 driver: each lane walks its own flagged pairs of the chunk and calls visit(pair).
+template <class Visit>
+__device__ __forceinline__ void walk_flagged(uint32_t summary, int w0, const uint32_t* words, Visit&& visit RT_STAMP_PARAM) {
+    uint32_t cur = 0;
+    int wbase = 0;
+    while (cur != 0u || summary != 0u) {
+        RT_COUNT(0);
+        if (cur == 0u) {
+            const int wi = __builtin_ctz(summary);
+            summary &= summary - 1u;
+            cur = words[wi * kScanBlock];
+            wbase = (w0 + wi) * 32;
+        }
+        const int p = __builtin_clz(cur);
+        cur &= ~(0x80000000u >> p);
+        visit(wbase + p);
+    }
+}
+
+__device__ __forceinline__ int group_words(const FilterGroup& fg) { return fg.n_ewords + (((fg.n_fpairs >> 3) + 3) >> 2); }
+
+// Spheres of one ray (o, d, a = d.lengthSquared() as Ray.h:8 caches it). `words` is this thread's
+// column of the block's flag-word array in LDS (stride kScanBlock). sph_prim: flattened primitive
+// index per sphere slot (-1 for pads). Requires ray_in_fast_range and a finite scene. On return h is exact.
+__device__ __forceinline__ void scan_spheres(const FilterGroup& sg, const int* __restrict__ sph_prim, V3 o, V3 d, float a, double t_min,
+                                             double t_max, HitState& h, uint32_t* words RT_STAMP_PARAM) {
+    const int n_words = group_words(sg);
+    if (n_words == 0) return;
+    const float tmin_lo = __double2float_rd(t_min), tmin_hi = __double2float_ru(t_min);
+    const float ia = __builtin_amdgcn_rcpf(a);
+    const FilterRay fr = filter_ray(sg, o, d, a, ia);
+    const f2 OX = {o.x, o.x}, OY = {o.y, o.y}, OZ = {o.z, o.z}, AA = {a, a};
     for (int w0 = 0; w0 < n_words; w0 += kMaskWords) {
         const int nw = n_words - w0 < kMaskWords ? n_words - w0 : kMaskWords;
-        // ---- level 1: one flag bit per pair (pair p of a word <-> bit 31 - p), words to LDS -------------
-        uint32_t summary = 0;
-        for (int wi = 0; wi < nw; ++wi) {
-            const int gw = w0 + wi;
-            uint32_t flagged;
-            if (gw < sg.n_ewords) {                            // exact group: every real pair
-                const int real = sg.n_epairs - gw * 32;
-                flagged = real >= 32 ? 0xffffffffu : ~(0xffffffffu >> real);
-            } else {
-                int batch = (gw - sg.n_ewords) * 4;
-                const int nb = n_fbatches - batch < 4 ? n_fbatches - batch : 4;
-                uint32_t m = 0;
-                for (int bb = 0; bb < nb; ++bb, ++batch) {
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int j = batch * 8 + jj;
-                        f2 X = fx[j], Y = fy[j], Z = fz[j], K = fk[j];
-                        f2 bq = __builtin_elementwise_fma(-Z, DZ, __builtin_elementwise_fma(-Y, DY, __builtin_elementwise_fma(-X, DX, OD)));
-                        f2 Q = __builtin_elementwise_fma(NA, K, MM);
-                        Q = __builtin_elementwise_fma(WX, X, Q);
-                        Q = __builtin_elementwise_fma(WY, Y, Q);
-                        Q = __builtin_elementwise_fma(WZ, Z, Q);
-                        f2 T = __builtin_elementwise_fma(bq, bq, Q);   // >= 0 (sign bit clear): flagged
-                        m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x) & __float_as_uint(T.y), 31);
-                    }
-                }
-                if (nb < 4) m = (m << (32 - 8 * nb)) | (0xffffffffu >> (8 * nb));
-                flagged = ~m;
-            }
-            words[wi * kScanBlock] = flagged;
-            summary |= (flagged != 0u ? 1u : 0u) << wi;
-        }
+        const uint32_t summary = filter_words(sg, fr, w0, nw, words);
         RT_STAMP(2);
-        // ---- level 2: each lane walks its own flagged pairs ---------------------------------------------
-        uint32_t cur = 0;
-        int wbase = 0;
-        while (cur != 0u || summary != 0u) {
-            RT_COUNT(0);
-            if (cur == 0u) {
-                const int wi = __builtin_ctz(summary);
-                summary &= summary - 1u;
-                cur = words[wi * kScanBlock];
-                wbase = (w0 + wi) * 32;
-            }
-            const int p = __builtin_clz(cur);
-            cur &= ~(0x80000000u >> p);
-            const int pair = wbase + p;
+        walk_flagged(summary, w0, words, [&](int pair) {
             const float4 A = sg.fq[2 * pair], B = sg.fq[2 * pair + 1];
             const f2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, r2 = {B.z, B.w};
             const f2 x = OX - cx, y = OY - cy, z = OZ - cz;
-            const f2 b = x * DX + y * DY + z * DZ;        // dotProduct(originCenter, direction), shapes.h:83
-            const f2 c = x * x + y * y + z * z - r2;      // lengthSquared() - radiusSquared, shapes.h:84
-            const f2 D = b * b - AA * c;                  // shapes.h:86
+            const f2 b = x * fr.DX + y * fr.DY + z * fr.DZ;   // dotProduct(originCenter, direction), shapes.h:83
+            const f2 c = x * x + y * y + z * z - r2;          // lengthSquared() - radiusSquared, shapes.h:84
+            const f2 D = b * b - AA * c;                      // shapes.h:86
             uint32_t pend = (D.x >= 0.0f ? 1u : 0u) | (D.y >= 0.0f ? 2u : 0u);   // mostly 0 or one bit
             while (pend != 0u) {
                 const bool second = (pend & 1u) == 0u;
@@ -233,7 +257,7 @@ __device__ __forceinline__ void scan_spheres(const SphereGroups& sg, const int* 
                 sphere_candidate(a, ia, second ? b.y : b.x, second ? D.y : D.x, sph_prim[2 * pair + (second ? 1 : 0)], t_min, t_max, tmin_lo,
                                  tmin_hi, h RT_STAMP_ARG);
             }
-        }
+        } RT_STAMP_ARG);
         RT_STAMP(3);
     }
     if (h.dD >= 0.0f) { RT_COUNT(2); resolve_exact(a, t_min, t_max, h, false, 0.0f, 0.0f, -1); }

@@ -12,7 +12,7 @@ for f in glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recurs
     lines.append("== kernel stats (%s)" % os.path.relpath(f, out))
     for row in csv.DictReader(open(f)):
         lines.append("%-60s calls=%s avg_ns=%s total_ns=%s pct=%s" % (row["Name"][:60], row["Calls"], row["AverageNs"], row["TotalDurationNs"], row["Percentage"]))
-for p in ("pmc1", "pmc2"):
+for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
     for f in glob.glob(os.path.join(out, p, "**", "*counter_collection.csv"), recursive=True):
         acc = defaultdict(lambda: defaultdict(float))
         n = defaultdict(int)
