@@ -55,9 +55,12 @@ def cpu_baseline(scene, wl, budget_s=12.0):
     reduced frame). Preferred: the reference itself (oracle/_ref/ref_harness, built in the build
     container from the unmodified reference sources; single-threaded by construction). Otherwise the
     oracle port (oracle/librt_oracle.so), also on one thread."""
-    sw, sh, sspp = 320, 180, 2
+    # sized for roughly 10-20 s of single-core work per leg on the reference / port
+    sw, sh, sspp = 640, 360, 12
     if wl["scene"] == "builtin":
-        sspp = 16
+        sspp = 64          # 4x BASELINE.json configs[0] (640x360, 16 spp)
+    elif wl["scene"] in ("tris", "mixed"):
+        sw, sh, sspp = 160, 90, 2
     out = {}
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -70,7 +73,7 @@ def cpu_baseline(scene, wl, budget_s=12.0):
     # port, all the cores this job may use
     ncore = min(16, os.cpu_count() or 1)
     t0 = time.perf_counter()
-    _, rays_mt = O.render(scene, sw, sh, sspp * 4, wl["depth"], rng_mode=1, seed64=1, math_mode=1, n_threads=ncore)
+    _, rays_mt = O.render(scene, sw, sh, sspp * 8, wl["depth"], rng_mode=1, seed64=1, math_mode=1, n_threads=ncore)
     dt_mt = time.perf_counter() - t0
     port["all_cores"] = dict(value=rays_mt / dt_mt / 1e6, unit="Mrays/s", cores=ncore)
     out = port
@@ -84,7 +87,7 @@ def cpu_baseline(scene, wl, budget_s=12.0):
                 open(sp, "w").write(scene.to_text())
                 t0 = time.perf_counter()
                 r = subprocess.run([harness, "render", sp, str(sw), str(sh), str(sspp), str(wl["depth"]), "1", "2", "3"],
-                                   capture_output=True, text=True, timeout=120)
+                                   capture_output=True, text=True, timeout=300)
                 dt_ref = time.perf_counter() - t0
             if r.returncode == 0:
                 # the harness prints "... X s (Y Msamples/s)"; rays/sample taken from the port run
@@ -111,7 +114,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from ray_amd import api, scenes
+    from ray_amd import api, dist as rdist, scenes
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -140,25 +143,19 @@ def main():
     accum = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     rays = torch.zeros(1, dtype=torch.int64, device=dev)
 
-    # work split: spp-split (every rank renders all pixels, a slice of the samples, then all-reduce)
-    # or tile-split (every rank renders all samples of a band of rows, then all-reduce of disjoint bands)
-    if wl["split"] == "spp" or world == 1:
-        s0 = spp * rank // world
-        s1 = spp * (rank + 1) // world
-        y0, yc = 0, H
-    else:
-        s0, s1 = 0, spp
-        y0 = H * rank // world
-        yc = H * (rank + 1) // world - y0
+    # work split (ray_amd/dist.py): spp-split = every rank renders all pixels and a slice of the samples;
+    # tile-split = every rank renders all samples of a band of rows; both end in one all-reduce
+    pl = rdist.plan(wl["split"], W, H, spp, rank, world)
+    s0, s1 = pl["spp_begin"], pl["spp_begin"] + pl["spp_count"]
+    y0, yc = pl["y_begin"], pl["y_count"]
     seed = 0xC0FFEE
 
     def step():
-        if wl["split"] == "tile" and world > 1:
+        if pl["zero_first"]:
             accum.zero_()
         ctx.render_into(W, H, accum, s1 - s0, depth, seed=seed, flags=0, y_begin=y0, y_count=yc, spp_begin=s0, rays=rays)
         ms, _ = ctx.last_kernel_ms()
-        if world > 1:
-            dist.all_reduce(accum)
+        rdist.reduce_accumulators(accum, world)
         return ms
 
     def sync():

@@ -28,6 +28,7 @@ using namespace rt;
 // ================================================================================================
 struct DevScene {
     int n_sph, n_rect, n_tri, n_prims;
+    int n_rect_xy, n_rect_xz;              // the rect arrays are sorted by axis: XY first, then XZ, then YZ
     const float4* __restrict__ sph;        // [n_sph]  (cx, cy, cz, r)
     const int* __restrict__ sph_prim;      // [n_sph]  flattened primitive index, ascending
     const double* __restrict__ rect;       // [n_rect][5] (a0, a1, b0, b1, k)
@@ -100,19 +101,50 @@ RT_DEV bool sphere_t(const Ray& r, float4 s, double t_min, double bt, int idx, i
 
 // rectangle / xz_rect / yz_rect ::hit, shapes.h:172-180, 238-247, 304-312 (all-double arithmetic:
 // k and the bounds are doubles in the reference)
-RT_DEV bool rect_t(const Ray& r, int axis, const double* __restrict__ q, double t_min, double bt, int idx, int bi,
-                   double* t_out) {
-    float ok, dk, oa, da, ob, db;
-    if (axis == 0) { ok = r.o.z; dk = r.d.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
-    else if (axis == 1) { ok = r.o.y; dk = r.d.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
-    else { ok = r.o.x; dk = r.d.x; oa = r.o.y; da = r.d.y; ob = r.o.z; db = r.d.z; }
-    double t = (q[4] - double(ok)) / double(dk);
+// (ok, dk): origin / direction component along the rect's normal; (oa, da), (ob, db): in-plane components
+RT_DEV bool rect_core(float ok, float dk, float oa, float da, float ob, float db, double q0, double q1, double q2, double q3, double k,
+                      double t_min, double bt, int idx, int bi, double* t_out) {
+    double t = (k - double(ok)) / double(dk);
     if (reject_t(t, t_min, bt, idx, bi)) return false;
     double a = double(oa) + t * double(da);
     double b = double(ob) + t * double(db);
-    if (a < q[0] || a > q[1] || b < q[2] || b > q[3]) return false;
+    if (a < q0 || a > q1 || b < q2 || b > q3) return false;
     *t_out = t;
     return true;
+}
+template <int AXIS>
+RT_DEV bool rect_axis_t(const Ray& r, const double* __restrict__ q, double t_min, double bt, int idx, int bi, double* t_out) {
+    const float ok = AXIS == 0 ? r.o.z : (AXIS == 1 ? r.o.y : r.o.x), dk = AXIS == 0 ? r.d.z : (AXIS == 1 ? r.d.y : r.d.x);
+    const float oa = AXIS == 2 ? r.o.y : r.o.x, da = AXIS == 2 ? r.d.y : r.d.x;
+    const float ob = AXIS == 0 ? r.o.y : r.o.z, db = AXIS == 0 ? r.d.y : r.d.z;
+    return rect_core(ok, dk, oa, da, ob, db, q[0], q[1], q[2], q[3], q[4], t_min, bt, idx, bi, t_out);
+}
+// branches, not selects: a select of ray components by a run-time axis becomes an indexed load from a
+// copy of the ray in scratch memory
+RT_DEV bool rect_t(const Ray& r, int axis, const double* __restrict__ q, double t_min, double bt, int idx, int bi,
+                   double* t_out) {
+    if (axis == 0) return rect_axis_t<0>(r, q, t_min, bt, idx, bi, t_out);
+    if (axis == 1) return rect_axis_t<1>(r, q, t_min, bt, idx, bi, t_out);
+    return rect_axis_t<2>(r, q, t_min, bt, idx, bi, t_out);
+}
+// the rects of one axis, [j0, j1) of the axis-sorted rect arrays; wave-uniform data through scalar loads
+typedef const double __attribute__((address_space(4)))* cdp;
+typedef const int __attribute__((address_space(4)))* cip;
+template <int AXIS>
+__device__ __forceinline__ void scan_rects(const double* __restrict__ rect, const int* __restrict__ rect_prim, int j0, int j1, const Ray& r,
+                                           double t_min, double& bt, int& bi, bool& saw_nan) {
+    const float ok = AXIS == 0 ? r.o.z : (AXIS == 1 ? r.o.y : r.o.x), dk = AXIS == 0 ? r.d.z : (AXIS == 1 ? r.d.y : r.d.x);
+    const float oa = AXIS == 2 ? r.o.y : r.o.x, da = AXIS == 2 ? r.d.y : r.d.x;
+    const float ob = AXIS == 0 ? r.o.y : r.o.z, db = AXIS == 0 ? r.d.y : r.d.z;
+    cdp q = (cdp)(uintptr_t)rect;
+    cip pr = (cip)(uintptr_t)rect_prim;
+    for (int j = j0; j < j1; ++j) {
+        double t;
+        const int idx = pr[j];
+        if (rect_core(ok, dk, oa, da, ob, db, q[5 * j], q[5 * j + 1], q[5 * j + 2], q[5 * j + 3], q[5 * j + 4], t_min, bt, idx, bi, &t)) {
+            if (t != t) saw_nan = true; else { bt = t; bi = idx; }
+        }
+    }
 }
 
 // Triangle (not in the reference; DESIGN.md "triangles"): Moeller-Trumbore, FP32, NaN = miss.
@@ -195,13 +227,9 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
         scan_spheres(sc.sg, sc.sph_prim, r.o, r.d, r.dl2, t_min, t_max, hs, words RT_STAMP_ARG);
         h.t = hs.bt; h.prim = hs.idx;
         bool saw_nan = false;
-        for (int j = 0; j < sc.n_rect; ++j) {
-            double t;
-            int idx = sc.rect_prim[j];
-            if (rect_t(r, sc.rect_axis[j], sc.rect + 5 * j, t_min, h.t, idx, h.prim, &t)) {
-                if (t != t) saw_nan = true; else { h.t = t; h.prim = idx; }
-            }
-        }
+        scan_rects<0>(sc.rect, sc.rect_prim, 0, sc.n_rect_xy, r, t_min, h.t, h.prim, saw_nan);
+        scan_rects<1>(sc.rect, sc.rect_prim, sc.n_rect_xy, sc.n_rect_xy + sc.n_rect_xz, r, t_min, h.t, h.prim, saw_nan);
+        scan_rects<2>(sc.rect, sc.rect_prim, sc.n_rect_xy + sc.n_rect_xz, sc.n_rect, r, t_min, h.t, h.prim, saw_nan);
         if (!saw_nan) scan_triangles(sc, r, t_min, h, words RT_STAMP_ARG);
         ok = !saw_nan;
     }
@@ -948,9 +976,22 @@ int rt_upload_scene(const RtScene* s) {
         tri.swap(tri2); tri_prim.swap(prim2);
     }
 
+    int n_rect_axis[3] = {0, 0, 0};
+    {   // rects sorted by axis (stable), so that the fast scan runs one loop per axis
+        std::vector<double> rect2; std::vector<int> axis2, prim2;
+        for (int ax = 0; ax < 3; ++ax)
+            for (size_t j = 0; j < rect_axis.size(); ++j) if (rect_axis[j] == ax) {
+                prim_local[rect_prim[j]] = int(axis2.size());
+                rect2.insert(rect2.end(), &rect[5 * j], &rect[5 * j] + 5); axis2.push_back(ax); prim2.push_back(rect_prim[j]);
+                ++n_rect_axis[ax];
+            }
+        rect.swap(rect2); rect_axis.swap(axis2); rect_prim.swap(prim2);
+    }
+
     HIP_OK(hipStreamSynchronize(g.stream));
     free_scene();
     DevScene ds{};
+    ds.n_rect_xy = n_rect_axis[0]; ds.n_rect_xz = n_rect_axis[1];
     ds.n_sph = int(sph.size()); ds.n_rect = int(rect_axis.size()); ds.n_tri = int(tri_prim.size()); ds.n_prims = s->n_prims;
     if (upload(sph, &ds.sph) || upload(sph_prim, &ds.sph_prim) || upload(rect, &ds.rect) || upload(rect_axis, &ds.rect_axis) ||
         upload(rect_prim, &ds.rect_prim) || upload(tri, &ds.tri) || upload(tri_prim, &ds.tri_prim) ||

@@ -1,0 +1,46 @@
+"""Multi-GPU split of one frame, one process per GPU under torch.distributed.
+
+Every pixel-sample is independent (the counter RNG is keyed by (seed, pixel, sample)), so a frame is
+sharded with no data-path exchange except ONE sum of the FP32 accumulators at the end:
+  * spp-split: rank r renders samples [spp*r/N, spp*(r+1)/N) of every pixel;
+  * tile-split: rank r renders all samples of the row band [H*r/N, H*(r+1)/N) into a zeroed accumulator.
+Both end with all_reduce(sum) over the [H][W][4] accumulator (RCCL over xGMI with backend "nccl",
+gloo on CPU in the tests). The functions here are pure host logic: they are what bench.py runs and
+what tests/test_dist_cpu.py exercises with world_size 2 on CPU."""
+from __future__ import annotations
+
+
+def spp_split(spp: int, rank: int, world: int):
+    """Sample range of `rank`: (begin, count). Ranges tile [0, spp) in rank order."""
+    if world < 1 or not 0 <= rank < world or spp < 0:
+        raise ValueError(f"bad split spp={spp} rank={rank} world={world}")
+    b, e = spp * rank // world, spp * (rank + 1) // world
+    return b, e - b
+
+
+def row_split(height: int, rank: int, world: int):
+    """Row band of `rank`: (y_begin, y_count). Bands tile [0, height) in rank order."""
+    if world < 1 or not 0 <= rank < world or height < 0:
+        raise ValueError(f"bad split height={height} rank={rank} world={world}")
+    b, e = height * rank // world, height * (rank + 1) // world
+    return b, e - b
+
+
+def plan(split: str, W: int, H: int, spp: int, rank: int, world: int) -> dict:
+    """What `rank` renders: rows [y_begin, +y_count), samples [spp_begin, +spp_count), and whether its
+    accumulator must be zeroed first (tile-split: the other ranks' bands must contribute zeros)."""
+    if split not in ("spp", "tile"):
+        raise ValueError(f"unknown split {split!r}")
+    if split == "spp" or world == 1:
+        s0, sc = spp_split(spp, rank, world)
+        return dict(y_begin=0, y_count=H, spp_begin=s0, spp_count=sc, zero_first=False)
+    y0, yc = row_split(H, rank, world)
+    return dict(y_begin=y0, y_count=yc, spp_begin=0, spp_count=spp, zero_first=True)
+
+
+def reduce_accumulators(accum, world: int):
+    """Sum the per-rank accumulators in place on every rank (no-op for one rank)."""
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(accum)
+    return accum
