@@ -65,6 +65,9 @@ RT_DEV double div64(double n, const Recip64& R) {
 RT_DEV bool recip_range_ok(double d) { return d >= 1.0e-150 && d <= 1.0e150; }   // false for NaN, 0, inf, negative
 
 RT_DEV V3 normalized(V3 v) {
+#if defined(RT_EXPERIMENT_FAST_NORMALIZE) && defined(__HIP_DEVICE_COMPILE__)
+    { float r_ = __builtin_amdgcn_rsqf(length_squared(v)); return v3(v.x * r_, v.y * r_, v.z * r_); }   // timing experiment only: wrong bits
+#endif
     double len = len2_f64(v);
     if (__builtin_fabs(len - 1.0) <= 0.000000000001) return v;
     if (!(__builtin_fabs(len) <= 0.000000000001)) {

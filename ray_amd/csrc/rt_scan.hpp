@@ -56,13 +56,15 @@ constexpr float kMarginKTri = 160.0f * 5.9604644775390625e-08f;   // + the FP32 
 struct Stamps {
     unsigned long long t[8];     // 0 assign+new sample, 1 -, 2 filter, 3 candidate walk, 4 rect+tri, 5 shade, 6 unwind+store, 7 other
     unsigned long long last;
-    unsigned int cnt[4];         // counted on the first active lane only: 0 walk passes, 1 FP64 passes in the walk, 2 final FP64 passes, 3 scans
+    unsigned int cnt[4];         // 0 walk passes and 3 scans (first active lane only); 1 flagged sphere pairs and 2 sphere candidates (every lane)
 };
 #define RT_STAMP(i) do { unsigned long long now_ = __builtin_amdgcn_s_memtime(); stp.t[i] += now_ - stp.last; stp.last = now_; } while (0)
 #define RT_COUNT(i) do { if ((__ffsll((long long)__ballot(1)) - 1) == int(threadIdx.x & 63)) ++stp.cnt[i]; } while (0)
+#define RT_COUNT_LANES(i) do { ++stp.cnt[i]; } while (0)
 #define RT_STAMP_PARAM , Stamps& stp
 #define RT_STAMP_ARG , stp
 #else
+#define RT_COUNT_LANES(i) do {} while (0)
 #define RT_STAMP(i) do {} while (0)
 #define RT_COUNT(i) do {} while (0)
 #define RT_STAMP_PARAM
@@ -136,8 +138,8 @@ __device__ __forceinline__ void sphere_candidate(float a, float ia, float b, flo
     const bool take = known && !skip && hi < h.blo;              // in front of the best: new best, FP64 deferred
     h.idx = take ? idx : h.idx; h.db = take ? b : h.db; h.dD = take ? D : h.dD;
     h.blo = take ? lo : h.blo; h.bhi = take ? hi : h.bhi;
+    RT_COUNT_LANES(2);
     if (!skip && !take) {                                        // overlap, tie, or a root within rounding of t_min
-        RT_COUNT(1);
         resolve_exact(a, t_min, t_max, h, true, b, D, idx);
     }
 }
@@ -153,6 +155,11 @@ struct FilterRay {
     f2 DX, DY, DZ, OD, MM, NA, WX, WY, WZ;
 };
 __device__ __forceinline__ FilterRay filter_ray(const FilterGroup& fg, V3 o, V3 d, float a, float ia) {
+    if (fg.n_fpairs == 0) {   // wave-uniform: only always-flagged pairs, the constants are not read
+        FilterRay z; z.DX = z.DY = z.DZ = f2{d.x, d.y}; z.OD = z.MM = z.NA = z.WX = z.WY = z.WZ = f2{0.0f, 0.0f};
+        z.DX = f2{d.x, d.x}; z.DY = f2{d.y, d.y}; z.DZ = f2{d.z, d.z};
+        return z;
+    }
     V3 orel = o - v3(fg.gx, fg.gy, fg.gz);
     float s = -(orel.x * d.x + orel.y * d.y + orel.z * d.z) * ia;
     V3 op = v3(__builtin_fmaf(s, d.x, orel.x), __builtin_fmaf(s, d.y, orel.y), __builtin_fmaf(s, d.z, orel.z));   // a point of the line near g
@@ -244,6 +251,7 @@ __device__ __forceinline__ void scan_spheres(const FilterGroup& sg, const int* _
         const uint32_t summary = filter_words(sg, fr, w0, nw, words);
         RT_STAMP(2);
         walk_flagged(summary, w0, words, [&](int pair) {
+            RT_COUNT_LANES(1);
             const float4 A = sg.fq[2 * pair], B = sg.fq[2 * pair + 1];
             const f2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, r2 = {B.z, B.w};
             const f2 x = OX - cx, y = OY - cy, z = OZ - cz;
@@ -260,7 +268,7 @@ __device__ __forceinline__ void scan_spheres(const FilterGroup& sg, const int* _
         } RT_STAMP_ARG);
         RT_STAMP(3);
     }
-    if (h.dD >= 0.0f) { RT_COUNT(2); resolve_exact(a, t_min, t_max, h, false, 0.0f, 0.0f, -1); }
+    if (h.dD >= 0.0f) { resolve_exact(a, t_min, t_max, h, false, 0.0f, 0.0f, -1); }
     RT_STAMP(3);
 }
 

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Timing experiment: render a workload with an alternative build of the library (results may be wrong).
+    python tools/exp_bench.py <lib.so> [workload] [spp]"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from ray_amd import api, scenes  # noqa: E402
+import bench  # noqa: E402
+lib = sys.argv[1]
+wl = dict(bench.WORKLOADS[sys.argv[2] if len(sys.argv) > 2 else "c3"])
+spp = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+ctx = api.Context(0, lib_path=os.path.join(ROOT, lib))
+ctx.upload_scene(scenes.get_scene(wl["scene"], **wl["kw"]))
+W, H = wl["W"], wl["H"]
+acc = ctx.alloc(W * H * 16).zero()
+rays = ctx.alloc(8).zero()
+best = 1e9
+for _ in range(3):
+    rays.zero()
+    ctx.render_into(W, H, acc, spp, wl["depth"], seed=1, rays=rays)
+    best = min(best, ctx.last_kernel_ms()[0])
+n = int(rays.to_numpy("uint64", (1,))[0])
+print(f"{lib} {wl['desc']} spp={spp}: {best:.2f} ms, {n / best / 1e3:.0f} Mrays/s")
+ctx.close()

@@ -35,5 +35,5 @@ scans = t[11]
 for n, v in zip(names, t[:8]):
     print(f"  {n:22s} {100.0 * v / tot:6.2f} %   {v / max(scans, 1):9.0f} cycles per wave-scan")
 print(f"  wave-scans {scans}, rays per wave-scan {n_rays / max(scans, 1):.1f} (64 = all lanes busy)")
-print(f"  walk passes per wave-scan {t[8] / max(scans, 1):.2f}, FP64 root passes {t[9] / max(scans, 1):.2f}, exact-group FP64 passes {t[10] / max(scans, 1):.2f}")
+print(f"  walk passes per wave-scan {t[8] / max(scans, 1):.2f}; per ray: flagged sphere pairs {t[9] / max(n_rays, 1):.2f}, sphere candidates (d >= 0) {t[10] / max(n_rays, 1):.2f}")
 ctx.close()
