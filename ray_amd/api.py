@@ -182,3 +182,39 @@ class Context:
         ms, n = C.c_float(0), C.c_int(0)
         self.lib.rt_last_kernel_ms(C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+
+class Progressive:
+    """RayView::go (rayview.cpp:98-117) for the GPU: each go() is one time slice of full-frame passes that
+    ACCUMULATE into one device accumulator; sample indices continue across slices, reset() (scene or
+    camera changed) starts again from sample 0. Mirrors ProgressiveView of ray_amd/host/ray_amd_host.h."""
+
+    def __init__(self, ctx: Context, W: int, H: int, depth: int, seed: int = 0):
+        self.ctx, self.W, self.H, self.depth, self.seed = ctx, W, H, depth, seed
+        self.acc = ctx.alloc(W * H * 16)
+        self.done, self.per_pass = 0, 1
+
+    def reset(self, scene=None):
+        if scene is not None:
+            self.ctx.upload_scene(scene)
+        self.done = 0
+
+    def go(self, budget_ms: float = 16.0) -> int:
+        used = 0.0
+        while True:
+            flags = RENDER_ACCUMULATE if self.done else 0
+            self.ctx.render_into(self.W, self.H, self.acc, self.per_pass, self.depth, seed=self.seed, flags=flags, spp_begin=self.done)
+            ms, _ = self.ctx.last_kernel_ms()
+            self.done += self.per_pass
+            used += ms
+            per_sample = ms / self.per_pass
+            nxt = int(0.5 * budget_ms / per_sample) if per_sample > 0 else self.per_pass * 2
+            self.per_pass = min(max(nxt, 1), 64)
+            if used + ms > budget_ms:
+                return self.done
+
+    def accumulators(self) -> np.ndarray:
+        return self.acc.to_numpy(np.float32, (self.H, self.W, 4))
+
+    def image(self) -> np.ndarray:
+        return self.ctx.tonemap(self.W, self.H, self.acc)

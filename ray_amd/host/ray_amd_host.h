@@ -334,4 +334,61 @@ inline std::vector<uint32_t> renderAll(rt_host::Session& s, int width, int heigh
     return out;
 }
 
+// RayView::go (rayview.cpp:98-117) for the GPU. The reference spends each 16 ms slice on random
+// pixels, every one rendered with all its samples and overwritten on the next visit; here a slice is
+// one or more FULL-FRAME passes of a few samples each, accumulated (RT_RENDER_ACCUMULATE), so the
+// picture refines everywhere at once. Sample indices continue across slices (pass k renders samples
+// [done, done + n) of every pixel), so N slices of the same scene give exactly the samples of one
+// N-slice-long render. A scene or camera change (the sphere-Y slider, WASD: rayview.cpp:130-184) is
+// reset(): re-upload and start again from sample 0.
+class ProgressiveView {
+public:
+    ProgressiveView(rt_host::Session& s, int width, int height, int max_depth, uint64_t seed = 0)
+        : s_(s), w_(width), h_(height), depth_(max_depth), seed_(seed), acc_(uint64_t(width) * height * 16), img_(uint64_t(width) * height * 4) {}
+    void reset(const std::vector<std::shared_ptr<shape>>& world, const std::shared_ptr<shape>& lights, const camera& cam,
+               const QVector3D& background = img::gradientBgVec) {
+        s_.upload(world, lights, background);
+        rt_host::check(rt_set_camera(&cam.rt()));
+        done_ = 0;
+    }
+    // One time slice: passes until budget_ms of kernel time are used (at least one pass). Returns the
+    // number of samples per pixel accumulated so far.
+    int go(double budget_ms = 16.0) {
+        double used = 0.0;
+        do {
+            rt_host::check(rt_render(w_, h_, 0, h_, done_, per_pass_, depth_, seed_, done_ == 0 ? 0u : RT_RENDER_ACCUMULATE,
+                                     (float*)acc_.p, nullptr));
+            float ms = 0.0f; int launches = 0;
+            rt_last_kernel_ms(&ms, &launches);
+            done_ += per_pass_;
+            used += ms;
+            const double per_sample = ms / per_pass_;   // size the next pass to about half a slice
+            int next = per_sample > 0.0 ? int(0.5 * budget_ms / per_sample) : per_pass_ * 2;
+            per_pass_ = next < 1 ? 1 : (next > 64 ? 64 : next);
+        } while (used + last_pass_estimate() <= budget_ms);
+        return done_;
+    }
+    int samples() const { return done_; }
+    // calc::rgbPerSamples + writeToImg over the accumulators (Format_RGB32, mirrored)
+    std::vector<uint32_t> image() {
+        std::vector<uint32_t> out(size_t(w_) * h_);
+        if (done_ == 0) return out;
+        rt_host::check(rt_tonemap(w_, h_, (const float*)acc_.p, 0, (uint32_t*)img_.p));
+        rt_host::check(rt_memcpy_d2h(out.data(), img_.p, out.size() * 4));
+        return out;
+    }
+    std::vector<float> accumulators() {
+        std::vector<float> out(size_t(w_) * h_ * 4);
+        rt_host::check(rt_memcpy_d2h(out.data(), acc_.p, out.size() * 4));
+        return out;
+    }
+private:
+    double last_pass_estimate() const { float ms = 0.0f; int l = 0; rt_last_kernel_ms(&ms, &l); return double(ms); }
+    rt_host::Session& s_;
+    int w_, h_, depth_;
+    uint64_t seed_;
+    rt_host::DevBuf acc_, img_;
+    int done_ = 0, per_pass_ = 1;
+};
+
 #endif  // RAY_AMD_HOST_H

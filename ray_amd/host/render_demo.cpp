@@ -49,6 +49,16 @@ int main(int argc, char** argv) {
         printf("rendered %dx%d spp=%d depth=%d: %.3f s, %llu rays, %.1f Mrays/s; centre ray hits prim %d t=%.9g colour (%g %g %g)\n",
                W, H, spp, depth, sec, (unsigned long long)rays, rays / sec * 1e-6, rec ? rec->rt_prim : -1, rec ? rec->t : 0.0,
                col.x(), col.y(), col.z());
+        // RayView::go: three 16 ms slices of progressive refinement, then a slider move (rayview.cpp:130-134)
+        ProgressiveView view(session, W, H, depth, seed);
+        view.reset(world, lights, cam);
+        int n = 0;
+        for (int slice = 0; slice < 3; ++slice) n = view.go(16.0);
+        std::vector<float> pacc = view.accumulators();
+        world[0]->center.setY(0.8f);
+        view.reset(world, lights, cam);
+        int n2 = view.go(16.0);
+        printf("progressive: %d samples/pixel after 3 slices (accumulator count %.0f), %d after the slider moved\n", n, pacc[3], n2);
         FILE* f = fopen("out.ppm", "wb");
         if (f) {
             fprintf(f, "P6\n%d %d\n255\n", W, H);

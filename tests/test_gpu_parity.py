@@ -259,3 +259,63 @@ def test_cpp_dropin_host_renderAll(rt, tmp_path):
     oacc, _ = O.render(sc, 96, 54, 4, 8, rng_mode=1, seed64=77, math_mode=1)
     assert O.same_values(acc, oacc)
     assert "centre ray hits prim 0" in r.stdout
+
+
+def test_progressive_slices_continue_the_sample_sequence(rt):
+    """RayView::go on the GPU (SURVEY.md 8f row 1): time slices accumulate full-frame passes; after any
+    number of slices the accumulators hold exactly samples [0, n) of every pixel, and reset() (scene
+    mutation, as the sphere-Y slider does) starts over."""
+    from ray_amd import api
+    sc = scenes.builtin_scene()
+    rt.upload_scene(sc)
+    W, H, depth = 96, 54, 8
+    pv = api.Progressive(rt, W, H, depth, seed=21)
+    n1 = pv.go(budget_ms=0.5)
+    n2 = pv.go(budget_ms=2.0)
+    assert 1 <= n1 < n2
+    acc = pv.accumulators()
+    assert (acc[..., 3] == n2).all()
+    oacc, _ = O.render(sc, W, H, n2, depth, rng_mode=1, seed64=21, math_mode=1, n_threads=8)
+    np.testing.assert_allclose(acc[..., :3], oacc[..., :3], rtol=3e-6, atol=1e-6)   # passes add partial sums
+    img = pv.image()
+    assert img.shape == (H, W) and (img >> 24 == 0xff).all()
+    moved = scenes.builtin_scene(sphere_y=0.8)
+    pv.reset(moved)
+    n3 = pv.go(budget_ms=0.2)
+    acc3 = pv.accumulators()
+    o3, _ = O.render(moved, W, H, n3, depth, rng_mode=1, seed64=21, math_mode=1, n_threads=8)
+    assert (acc3[..., 3] == n3).all()
+    np.testing.assert_allclose(acc3[..., :3], o3[..., :3], rtol=3e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,kw,W,H,rows", [
+    ("random", {"half": 11}, 3840, 2160, (5, 1080, 2154)),          # BASELINE.json configs[2]
+    ("tris", {"n": 71}, 1920, 1080, (400, 900)),                    # configs[3]
+    ("mixed", {"half": 11, "n": 71}, 3840, 2160, (1500,)),          # configs[4]
+    ("builtin", {}, 1920, 1080, (3, 540, 1079)),                    # configs[1]
+])
+def test_full_size_frame_properties(rt, name, kw, W, H, rows):
+    """BASELINE.json's GPU configs at their full frame sizes (the oracle needs hours there): every scan of a
+    1-spp frame equals the list-order loop (RT_RENDER_VERIFY), a frame cut into two sample ranges or
+    into two row bands reproduces the uncut frame, and the sample count lands in .w."""
+    sc = scenes.get_scene(name, **kw)
+    rt.upload_scene(sc)
+    depth = 8
+    full, rays = rt.render(W, H, 2, depth, seed=0xC0FFEE)
+    assert (full[..., 3] == 2).all() and np.isfinite(full).all() and rays > 2 * W * H
+    _, rays_v = rt.render(W, H, 1, depth, seed=0xC0FFEE, flags=4)
+    assert rt.verify_mismatches() == 0 and rays_v > W * H
+    acc = rt.alloc(W * H * 16).zero()
+    rt.render_into(W, H, acc, 1, depth, seed=0xC0FFEE, spp_begin=0)
+    rt.render_into(W, H, acc, 1, depth, seed=0xC0FFEE, spp_begin=1, flags=1)
+    assert O.same_values(acc.to_numpy(np.float32, (H, W, 4)), full)        # 2 samples: (a) + (b) is the same sum
+    acc.zero()
+    rt.render_into(W, H, acc, 2, depth, seed=0xC0FFEE, y_begin=0, y_count=H // 2 + 1)
+    rt.render_into(W, H, acc, 2, depth, seed=0xC0FFEE, y_begin=H // 2 + 1, y_count=H - (H // 2 + 1))
+    assert O.same_values(acc.to_numpy(np.float32, (H, W, 4)), full)
+    acc.free()
+    # a few rows of the frame against the oracle (bit-exact radiance sums and ray counts at full-size pixel coordinates)
+    for y in rows:
+        orow = np.zeros((H, W, 4), np.float32)
+        O.render(sc, W, H, 2, depth, rng_mode=1, seed64=0xC0FFEE, math_mode=1, y_begin=y, y_count=1, accum=orow)
+        assert O.same_values(full[y], orow[y])
