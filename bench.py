@@ -199,6 +199,13 @@ def main():
         k_ms = kernel_ms / max(args.steps, 1)
         flops_launch = local_rays / max(args.steps, 1) * fpr
         achieved = flops_launch / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        traffic = None   # HBM bytes per launch from the committed PMC passes, only for the exact configuration they ran
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(args.workload)
+            if tr and world == 1 and (tr["W"], tr["H"], tr["spp"]) == (W, H, spp):
+                traffic = tr["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "Mrays/s (incl. bounces)", "value": round(mrays, 3), "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -207,7 +214,7 @@ def main():
                        "primitives": int(flat["n_prims"]), "split": wl["split"] if world > 1 else "none",
                        "rays_per_frame": total_rays // max(args.steps, 1), "seed": seed},
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 4), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": None,
+                         "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
                          "kernel": "render_kernel", "kernel_ms": round(k_ms, 3), "flops_per_ray": fpr,
                          "accumulator_GBps": round(W * H * 16 * (2 if False else 1) / (k_ms * 1e-3) / 1e9, 3) if k_ms > 0 else None},
         }
