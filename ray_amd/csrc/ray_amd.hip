@@ -190,7 +190,8 @@ __device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const R
     return h;
 }
 
-// Triangles of one ray: the sphere filter of rt_scan.hpp on the triangles' bounding spheres (every hit
+// Triangles of one ray: the sphere filter of rt_scan.hpp on the bounding spheres of items of one or two
+// triangles (every hit
 // point lies inside its triangle's sphere by definition of the primitive, ray_amd_tri.h), then
 // tri_t on the flagged pairs. h is exact on entry and on return.
 __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r, double t_min, Hit& h, uint32_t* words RT_STAMP_PARAM) {
@@ -204,11 +205,11 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
         RT_STAMP(2);
         walk_flagged(summary, w0, words, [&](int pair) {
 #pragma unroll 1
-            for (int hh = 0; hh < 2; ++hh) {
-                const int slot = 2 * pair + hh;
+            for (int hh = 0; hh < 4; ++hh) {   // two items of up to two triangles each
+                const int slot = 4 * pair + hh;
                 const int idx = sc.tri_prim[slot];
                 double t;
-                if (tri_t(r, sc.tri + 16 * slot, t_min, h.t, idx, h.prim, &t)) { h.t = t; h.prim = idx; }
+                if (idx >= 0 && tri_t(r, sc.tri + 16 * slot, t_min, h.t, idx, h.prim, &t)) { h.t = t; h.prim = idx; }
             }
         } RT_STAMP_ARG);
         RT_STAMP(3);
@@ -954,24 +955,60 @@ int rt_upload_scene(const RtScene* s) {
         sph.swap(sph2); sph_prim.swap(prim2);
     }
     {
+        // Filter items of the triangle group: ONE bounding sphere per item of up to two triangles. Two
+        // consecutive triangles share an item when the sphere around both bounding spheres is at most 15 %
+        // wider than the larger of the two (the two halves of a quad have the same minimal sphere: the cell's).
         const size_t nt = tri_prim.size();
-        std::vector<float4> bound(nt);
-        std::vector<float> r2k(nt);
+        std::vector<int> item_a, item_b;   // triangle indices of each item (item_b = -1: single)
+        std::vector<float4> bound;
+        std::vector<float> r2k;
+        auto joint = [&](size_t i, size_t j, double c[3]) {   // sphere around the bounding spheres of triangles i and j
+            const float *p = &tri[16 * i], *q = &tri[16 * j];
+            const double ri = std::sqrt(double(p[15])), rj = std::sqrt(double(q[15]));
+            for (int k = 0; k < 3; ++k) { c[k] = double(float(0.5 * (double(p[12 + k]) + double(q[12 + k])))); }
+            double ra = 0, rb_ = 0;
+            for (int k = 0; k < 3; ++k) { ra += (p[12 + k] - c[k]) * (p[12 + k] - c[k]); rb_ += (q[12 + k] - c[k]) * (q[12 + k] - c[k]); }
+            return std::max(std::sqrt(ra) + ri, std::sqrt(rb_) + rj);
+        };
         for (size_t i = 0; i < nt; ++i) {
             const float* q = &tri[16 * i];
-            const float rb = std::sqrt(q[15]);
-            bound[i] = make_float4(q[12], q[13], q[14], rb);
-            r2k[i] = q[15] * 1.0001f;   // the FP32 containment test of tri_t passes only inside this sphere
             for (int k = 0; k < 9; ++k) if (!(std::fabs(q[k]) <= 1.0e7f)) finite = false;
-            if (!(rb <= 1.0e7f)) finite = false;
+            if (!(std::sqrt(q[15]) <= 1.0e7f)) finite = false;
+        }
+        for (size_t i = 0; i < nt;) {
+            const float* q = &tri[16 * i];
+            const double ri = std::sqrt(double(q[15]));
+            double c[3];
+            if (finite && i + 1 < nt) {
+                const double rj = std::sqrt(double(tri[16 * (i + 1) + 15]));
+                const double r = joint(i, i + 1, c);
+                if (r <= 1.15 * std::max(ri, rj)) {
+                    const float rf = float(r * 1.000001) + 1.0e-30f;
+                    item_a.push_back(int(i)); item_b.push_back(int(i + 1));
+                    bound.push_back(make_float4(float(c[0]), float(c[1]), float(c[2]), rf));
+                    r2k.push_back(rf * rf * 1.0001f);   // the FP32 containment test of tri_t passes only inside this sphere
+                    i += 2;
+                    continue;
+                }
+            }
+            item_a.push_back(int(i)); item_b.push_back(-1);
+            bound.push_back(make_float4(q[12], q[13], q[14], float(ri)));
+            r2k.push_back(q[15] * 1.0001f);
+            ++i;
         }
         build_group(bound, r2k, kMarginKTri, finite, tgb);
         const float nanf_ = std::numeric_limits<float>::quiet_NaN();
-        std::vector<float> tri2(tgb.slot_item.size() * 16, nanf_);
-        std::vector<int> prim2(tgb.slot_item.size(), -1);
+        std::vector<float> tri2(tgb.slot_item.size() * 2 * 16, nanf_);   // two triangle slots per item slot
+        std::vector<int> prim2(tgb.slot_item.size() * 2, -1);
         for (size_t sl = 0; sl < tgb.slot_item.size(); ++sl) {
             const int it = tgb.slot_item[sl];
-            if (it >= 0) { std::copy(&tri[16 * it], &tri[16 * it] + 16, &tri2[16 * sl]); prim2[sl] = tri_prim[it]; prim_local[tri_prim[it]] = int(sl); }
+            if (it < 0) continue;
+            const int members[2] = {item_a[it], item_b[it]};
+            for (int h = 0; h < 2; ++h) if (members[h] >= 0) {
+                const size_t ts = 2 * sl + h;
+                std::copy(&tri[16 * members[h]], &tri[16 * members[h]] + 16, &tri2[16 * ts]);
+                prim2[ts] = tri_prim[members[h]]; prim_local[tri_prim[members[h]]] = int(ts);
+            }
         }
         tri.swap(tri2); tri_prim.swap(prim2);
     }
