@@ -338,3 +338,39 @@ def test_gpu_image_converges_to_the_reference_image(rt):
     # per-channel means too (a colour cast would hide in the overall mean)
     for c in range(3):
         assert abs(img[..., c].mean() - ref[..., c].mean()) / ref[..., c].mean() < 0.01
+
+
+def test_grazing_and_far_rays_match_oracle(rt):
+    """Stress of the conservative sphere filter: rays built to pass within a few ulp of a
+    sphere's silhouette, from origins 1 to 1e5 units away, with directions scaled over 12 binades, and
+    rays that start on a sphere's surface. hitFromList through the filter + exact path must still equal
+    the oracle's list-order loop bit for bit (primitive, t, hit record)."""
+    sc = scenes.get_scene("random", half=11)
+    rt.upload_scene(sc, set_camera=False)
+    flat = sc.flatten()
+    sph = flat["prim_data"][flat["prim_kind"] == 0][:, :4]
+    rng = np.random.default_rng(11)
+    n = 60000
+    pick = rng.integers(0, sph.shape[0], n)
+    c, r = sph[pick, :3], sph[pick, 3:4]
+    # a point on the silhouette circle seen from the origin side: p = c + r * u with u a random unit vector
+    u = rng.standard_normal((n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    # tangent direction at p: any vector orthogonal to u
+    w = rng.standard_normal((n, 3)); w -= (w * u).sum(1, keepdims=True) * u; w /= np.linalg.norm(w, axis=1, keepdims=True)
+    eps = rng.choice([0.0, 1e-7, -1e-7, 3e-7, -3e-7, 1e-5, -1e-5, 1e-3, -1e-3], n)[:, None]   # inside / outside the rim
+    p = c + r * (1.0 + eps) * u
+    dist = np.exp(rng.uniform(0.0, np.log(1e5), n))[:, None]
+    ro = (p - w * dist).astype(np.float32)
+    scale = np.exp2(rng.integers(-6, 7, (n, 1))).astype(np.float64)
+    rd = (w * scale).astype(np.float32)
+    # a quarter of the rays start ON a sphere (bounce rays do): origin = surface point, random direction
+    k = n // 4
+    ro[:k] = (c[:k] + r[:k] * u[:k]).astype(np.float32)
+    rd[:k] = rng.standard_normal((k, 3)).astype(np.float32)
+    got = rt.hit_rays(ro, rd, 0.001, np.inf)
+    ref = O.hit_rays(sc, ro, rd, 0.001, np.inf)
+    assert np.array_equal(got[0], ref[0])
+    assert O.bits_equal(got[1], ref[1])
+    for a, b in zip(got[2:], ref[2:]):
+        assert O.same_values(a, b)
+    assert 0.05 < (got[0] >= 0).mean() < 0.999
