@@ -335,11 +335,23 @@ __device__ __forceinline__ V3 light_random(const DevScene& sc, Rng& g, V3 o) {
 // bit-identical per-sample colours, not just "within tolerance". A specular level is stored with
 // pdf = -1 (a mixture pdf value is >= 0 or NaN, never -1).
 // ------------------------------------------------------------------------------------------------
+// The first kLdsLevels levels of every thread's stack live in LDS ([level][thread] float4, 4 KB per
+// level and block), deeper levels in HBM ([level][thread] over the whole grid): with depth <= 6 a frame
+// writes nothing but its accumulators to HBM.
+constexpr int kLdsLevels = 6;
 struct PathStack {
-    float4* __restrict__ base;   // [depth][stride] entries (w.xyz, pdf)
+    float4* lds;                 // this thread's column of the block's LDS stack (stride kScanBlock)
+    float4* __restrict__ base;   // HBM: [depth - kLdsLevels][stride] entries (w.xyz, pdf)
     uint32_t stride, tid;
-    RT_DEV void push(int level, V3 w, float pdf) { base[size_t(level) * stride + tid] = make_float4(w.x, w.y, w.z, pdf); }
-    RT_DEV float4 get(int level) const { return base[size_t(level) * stride + tid]; }
+    RT_DEV void push(int level, V3 w, float pdf) {
+        const float4 e = make_float4(w.x, w.y, w.z, pdf);
+        if (level < kLdsLevels) lds[level * kScanBlock] = e;
+        else base[size_t(level - kLdsLevels) * stride + tid] = e;
+    }
+    RT_DEV float4 get(int level) const {
+        if (level < kLdsLevels) return lds[level * kScanBlock];
+        return base[size_t(level - kLdsLevels) * stride + tid];
+    }
 };
 constexpr float kSpecularMark = -1.0f;
 
@@ -499,7 +511,8 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
     const int lane = threadIdx.x & 63;
     const int tiles_x = (ra.W + kTile - 1) / kTile, tiles_y = (ra.y_count + kTile - 1) / kTile;
     const int total = tiles_x * tiles_y * 64;
-    PathStack st; st.base = ra.stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ float4 s_stack[kLdsLevels * kBlock];
+    PathStack st; st.lds = s_stack + threadIdx.x; st.base = ra.stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
     const bool normals = (ra.flags & RT_RENDER_NORMALS) != 0;
     const int spp_end = ra.spp_begin + ra.spp_count;
     const Recip64 rpi = recip64(kPi);
@@ -666,7 +679,8 @@ __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene sc, long lo
                                                             float* __restrict__ rgb, float4* __restrict__ stack) {
     __shared__ uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
-    PathStack st; st.base = stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ float4 s_stack[kLdsLevels * kBlock];
+    PathStack st; st.lds = s_stack + threadIdx.x; st.base = stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
     for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
         Ray ray = make_ray(v3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), v3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]));
         Rng g; g.key(seed, uint32_t(i), 0u);
@@ -1127,7 +1141,7 @@ int rt_hit_rays(int64_t n, const float* d_origin, const float* d_dir, double t_m
 }
 
 static int ensure_stack(int depth, int grid) {
-    size_t need = size_t(depth > 0 ? depth : 1) * size_t(grid) * kBlock * sizeof(float4);
+    size_t need = size_t(depth > kLdsLevels ? depth - kLdsLevels : 1) * size_t(grid) * kBlock * sizeof(float4);
     if (need > g.stack_bytes) {
         HIP_OK(hipStreamSynchronize(g.stream));
         if (g.stack) HIP_OK(hipFree(g.stack));
