@@ -40,6 +40,8 @@ WORKLOADS = {
                desc="built-in sphere scene 1920x1080 64spp depth10"),
     "c4": dict(scene="tris", kw=dict(n=71), W=1920, H=1080, spp=64, depth=8, split="spp",
                desc="10k-triangle mesh 1920x1080 64spp depth8"),
+    "box": dict(scene="box", kw={}, W=1920, H=1080, spp=64, depth=10, split="spp",
+                desc="box_scene (rayview.cpp:262-378, 169 flattened primitives) 1920x1080 64spp depth10"),
     "c5": dict(scene="mixed", kw=dict(half=11, n=71), W=3840, H=2160, spp=1024, depth=8, split="tile",
                desc="mixed spheres+triangles 3840x2160 1024spp depth8"),
 }

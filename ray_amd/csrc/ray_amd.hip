@@ -32,6 +32,7 @@ struct DevScene {
     const float4* __restrict__ sph;        // [n_sph]  (cx, cy, cz, r)
     const int* __restrict__ sph_prim;      // [n_sph]  flattened primitive index, ascending
     const double* __restrict__ rect;       // [n_rect][5] (a0, a1, b0, b1, k)
+    const float* __restrict__ rect_f;      // [n_rect][5] (k nearest, a0 down, a1 up, b0 down, b1 up): FP32 enclosures
     const int* __restrict__ rect_axis;     // [n_rect] 0 = XY (z = k), 1 = XZ (y = k), 2 = YZ (x = k)
     const int* __restrict__ rect_prim;     // [n_rect]
     const float* __restrict__ tri;         // [n_tri][16] v0, e1, e2, unit normal, bounding sphere centre, radius^2 (ray_amd_tri.h)
@@ -130,19 +131,38 @@ RT_DEV bool rect_t(const Ray& r, int axis, const double* __restrict__ q, double 
 // the rects of one axis, [j0, j1) of the axis-sorted rect arrays; wave-uniform data through scalar loads
 typedef const double __attribute__((address_space(4)))* cdp;
 typedef const int __attribute__((address_space(4)))* cip;
+typedef const float __attribute__((address_space(4)))* cfp;
+// FP32 enclosures first (rect_f: k rounded to nearest, the bounds rounded outwards): a rect whose plane
+// distance or in-plane point is certainly out of range is skipped; only the others pay the reference's
+// FP64 division. Enclosure: tf = (kf - o) * rcp(d) is within et of the FP64 t (k's rounding u|k|/|d|, the
+// subtraction, rcp's 1 ulp and the product: < 5 ulp of |t| + u|k|/|d|; et takes 16 ulp of both), the
+// in-plane coordinate within ea = et*|da| + 16 ulp (|oa| + |tf*da|). inf / NaN never reject.
 template <int AXIS>
-__device__ __forceinline__ void scan_rects(const double* __restrict__ rect, const int* __restrict__ rect_prim, int j0, int j1, const Ray& r,
-                                           double t_min, double& bt, int& bi, bool& saw_nan) {
+__device__ __forceinline__ void scan_rects(const double* __restrict__ rect, const float* __restrict__ rect_f, const int* __restrict__ rect_prim,
+                                           int j0, int j1, const Ray& r, double t_min, float tminf, double& bt, int& bi, float& btf,
+                                           bool& saw_nan) {
     const float ok = AXIS == 0 ? r.o.z : (AXIS == 1 ? r.o.y : r.o.x), dk = AXIS == 0 ? r.d.z : (AXIS == 1 ? r.d.y : r.d.x);
     const float oa = AXIS == 2 ? r.o.y : r.o.x, da = AXIS == 2 ? r.d.y : r.d.x;
     const float ob = AXIS == 0 ? r.o.y : r.o.z, db = AXIS == 0 ? r.d.y : r.d.z;
+    const float idk = __builtin_amdgcn_rcpf(dk);
     cdp q = (cdp)(uintptr_t)rect;
+    cfp f = (cfp)(uintptr_t)rect_f;
     cip pr = (cip)(uintptr_t)rect_prim;
     for (int j = j0; j < j1; ++j) {
-        double t;
-        const int idx = pr[j];
-        if (rect_core(ok, dk, oa, da, ob, db, q[5 * j], q[5 * j + 1], q[5 * j + 2], q[5 * j + 3], q[5 * j + 4], t_min, bt, idx, bi, &t)) {
-            if (t != t) saw_nan = true; else { bt = t; bi = idx; }
+        const float kf = f[5 * j], a0 = f[5 * j + 1], a1 = f[5 * j + 2], b0 = f[5 * j + 3], b1 = f[5 * j + 4];
+        const float tf = (kf - ok) * idk;
+        const float et = ((__builtin_fabsf(kf) + __builtin_fabsf(ok)) * __builtin_fabsf(idk) + __builtin_fabsf(tf)) * 1.0e-6f;
+        const float pa = tf * da, pb = tf * db;
+        const float af = oa + pa, bf = ob + pb;
+        const float ea = et * __builtin_fabsf(da) + (__builtin_fabsf(oa) + __builtin_fabsf(pa)) * 1.0e-6f;
+        const float eb = et * __builtin_fabsf(db) + (__builtin_fabsf(ob) + __builtin_fabsf(pb)) * 1.0e-6f;
+        const bool out = tf - et > btf || tf + et < tminf || af + ea < a0 || af - ea > a1 || bf + eb < b0 || bf - eb > b1;
+        if (!out) {
+            double t;
+            const int idx = pr[j];
+            if (rect_core(ok, dk, oa, da, ob, db, q[5 * j], q[5 * j + 1], q[5 * j + 2], q[5 * j + 3], q[5 * j + 4], t_min, bt, idx, bi, &t)) {
+                if (t != t) saw_nan = true; else { bt = t; bi = idx; btf = __double2float_ru(t); }
+            }
         }
     }
 }
@@ -228,9 +248,13 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
         scan_spheres(sc.sg, sc.sph_prim, r.o, r.d, r.dl2, t_min, t_max, hs, words RT_STAMP_ARG);
         h.t = hs.bt; h.prim = hs.idx;
         bool saw_nan = false;
-        scan_rects<0>(sc.rect, sc.rect_prim, 0, sc.n_rect_xy, r, t_min, h.t, h.prim, saw_nan);
-        scan_rects<1>(sc.rect, sc.rect_prim, sc.n_rect_xy, sc.n_rect_xy + sc.n_rect_xz, r, t_min, h.t, h.prim, saw_nan);
-        scan_rects<2>(sc.rect, sc.rect_prim, sc.n_rect_xy + sc.n_rect_xz, sc.n_rect, r, t_min, h.t, h.prim, saw_nan);
+        if (sc.n_rect > 0) {
+            const float tminf = __double2float_rd(t_min);
+            float btf = __double2float_ru(h.t);
+            scan_rects<0>(sc.rect, sc.rect_f, sc.rect_prim, 0, sc.n_rect_xy, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
+            scan_rects<1>(sc.rect, sc.rect_f, sc.rect_prim, sc.n_rect_xy, sc.n_rect_xy + sc.n_rect_xz, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
+            scan_rects<2>(sc.rect, sc.rect_f, sc.rect_prim, sc.n_rect_xy + sc.n_rect_xz, sc.n_rect, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
+        }
         if (!saw_nan) scan_triangles(sc, r, t_min, h, words RT_STAMP_ARG);
         ok = !saw_nan;
     }
@@ -1038,13 +1062,23 @@ int rt_upload_scene(const RtScene* s) {
             }
         rect.swap(rect2); rect_axis.swap(axis2); rect_prim.swap(prim2);
     }
+    std::vector<float> rect_f(rect.size());
+    {
+        auto down = [](double v) { float f = float(v); return double(f) > v ? std::nextafterf(f, -INFINITY) : f; };
+        auto up = [](double v) { float f = float(v); return double(f) < v ? std::nextafterf(f, INFINITY) : f; };
+        for (size_t j = 0; j < rect_axis.size(); ++j) {
+            const double* q = &rect[5 * j];
+            float* f = &rect_f[5 * j];
+            f[0] = float(q[4]); f[1] = down(q[0]); f[2] = up(q[1]); f[3] = down(q[2]); f[4] = up(q[3]);
+        }
+    }
 
     HIP_OK(hipStreamSynchronize(g.stream));
     free_scene();
     DevScene ds{};
     ds.n_rect_xy = n_rect_axis[0]; ds.n_rect_xz = n_rect_axis[1];
     ds.n_sph = int(sph.size()); ds.n_rect = int(rect_axis.size()); ds.n_tri = int(tri_prim.size()); ds.n_prims = s->n_prims;
-    if (upload(sph, &ds.sph) || upload(sph_prim, &ds.sph_prim) || upload(rect, &ds.rect) || upload(rect_axis, &ds.rect_axis) ||
+    if (upload(sph, &ds.sph) || upload(sph_prim, &ds.sph_prim) || upload(rect, &ds.rect) || upload(rect_f, &ds.rect_f) || upload(rect_axis, &ds.rect_axis) ||
         upload(rect_prim, &ds.rect_prim) || upload(tri, &ds.tri) || upload(tri_prim, &ds.tri_prim) ||
         upload(prim_kind, &ds.prim_kind) || upload(prim_local, &ds.prim_local) || upload(prim_mat, &ds.prim_mat))
         return 1;
