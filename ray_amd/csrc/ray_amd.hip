@@ -312,7 +312,7 @@ __device__ __forceinline__ double light_pdf_value(const DevScene& sc, V3 o, V3 v
         if (verdict < 0) { double t; verdict = sphere_t(r, s, 0.001, kInf, 0, -1, &t) ? 1 : 0; }
         if (verdict == 0) return 0.0;
         V3 co = v3(s.x, s.y, s.z) - o;
-        double cos_theta_max = __builtin_sqrt(double(1 - s.w * s.w / length_squared(co)));
+        double cos_theta_max = sqrt64(double(1 - s.w * s.w / length_squared(co)));
         double solid_angle = 2 * kPi * (1 - cos_theta_max);
         return 1 / solid_angle;
     }
@@ -413,7 +413,7 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const
     } else if (mk == RT_MAT_DIELECTRIC) {                                   // hitPosition.h:253-287
         double refraction_ratio = rec.front_face ? sc.mat_inv_ir[m] : sc.mat_ir[m];
         float cos_theta = float(__builtin_fmin(double(dot(-unit_direction, rec.normal)), 1.0));
-        float sin_theta = float(__builtin_sqrt(double(1.0f - cos_theta * cos_theta)));
+        float sin_theta = float(sqrt64(double(1.0f - cos_theta * cos_theta)));
         bool cannot_refract = refraction_ratio * double(sin_theta) > 1.0;
         bool do_reflect = cannot_refract;
         if (!do_reflect) {
@@ -440,9 +440,9 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const
             Onb sb;
             sb.build_from_w(pick_light ? to_light : rec.normal);
             const double radius = double(sc.light_r), distance_squared = double(length_squared(to_light));
-            const double s1 = __builtin_sqrt(pick_light ? 1 - radius * radius / distance_squared : double(1 - r2));
+            const double s1 = sqrt64(pick_light ? 1 - radius * radius / distance_squared : double(1 - r2));
             const double z = pick_light ? 1 + r2 * (s1 - 1) : s1;
-            const double s2 = __builtin_sqrt(pick_light ? 1 - z * z : double(r2));
+            const double s2 = sqrt64(pick_light ? 1 - z * z : double(r2));
             const double phi = 2 * kPi * r1;
             double sn, cs;
             sincos_portable(phi, &sn, &cs);

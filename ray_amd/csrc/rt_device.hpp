@@ -64,6 +64,31 @@ RT_DEV double div64(double n, const Recip64& R) {
 }
 RT_DEV bool recip_range_ok(double d) { return d >= 1.0e-150 && d <= 1.0e150; }   // false for NaN, 0, inf, negative
 
+// IEEE double sqrt for 1e-280 <= x <= 1e280: the operations hipcc emits for __builtin_sqrt on gfx950
+// (v_rsq_f64 + Goldschmidt steps + two residual corrections) without the exponent scaling and the
+// 0 / inf / NaN selects, which only act outside this range. Callers that cannot prove the range use sqrt64().
+RT_DEV double sqrt64_in_range(double x) {
+#ifdef __HIP_DEVICE_COMPILE__
+    double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return g;
+#else
+    return __builtin_sqrt(x);
+#endif
+}
+RT_DEV double sqrt64(double x) {
+    if (x >= 1.0e-280 && x <= 1.0e280) return sqrt64_in_range(x);
+    return __builtin_sqrt(x);
+}
+
 RT_DEV V3 normalized(V3 v) {
 #if defined(RT_EXPERIMENT_FAST_NORMALIZE) && defined(__HIP_DEVICE_COMPILE__)
     { float r_ = __builtin_amdgcn_rsqf(length_squared(v)); return v3(v.x * r_, v.y * r_, v.z * r_); }   // timing experiment only: wrong bits
@@ -71,11 +96,12 @@ RT_DEV V3 normalized(V3 v) {
     double len = len2_f64(v);
     if (__builtin_fabs(len - 1.0) <= 0.000000000001) return v;
     if (!(__builtin_fabs(len) <= 0.000000000001)) {
-        double s = __builtin_sqrt(len);
-        if (recip_range_ok(s)) {   // always, unless a component is inf / NaN
+        if (len <= 1.0e280) {   // always, unless a component is inf / NaN; len > 1e-12 here
+            double s = sqrt64_in_range(len);
             Recip64 R = recip64(s);
             return v3(float(div64(double(v.x), R)), float(div64(double(v.y), R)), float(div64(double(v.z), R)));
         }
+        double s = __builtin_sqrt(len);
         return v3(float(double(v.x) / s), float(double(v.y) / s), float(double(v.z) / s));
     }
     return v3(0.0f, 0.0f, 0.0f);
@@ -191,7 +217,7 @@ RT_DEV V3 reflect(V3 v, V3 n) { return v - 2 * dot(v, n) * n; }
 RT_DEV V3 refract(V3 uv, V3 n, double etai_over_etat) {
     double cos_theta = __builtin_fmin(double(dot(-uv, n)), 1.0);
     V3 r_out_perp = float(etai_over_etat) * (uv + float(cos_theta) * n);
-    V3 r_out_parallel = float(-__builtin_sqrt(__builtin_fabs(1.0 - length_squared(r_out_perp)))) * n;
+    V3 r_out_parallel = float(-sqrt64(__builtin_fabs(1.0 - length_squared(r_out_perp)))) * n;
     return r_out_perp + r_out_parallel;
 }
 

@@ -90,7 +90,7 @@ __device__ __forceinline__ void hit_state_init(HitState& h, double t_max) {
 }
 // sphere::hit's root selection (shapes.h:90-97) in FP64 against the exact best
 __device__ __forceinline__ void exact_accept(float a, float b, float D, int idx, double t_min, HitState& h) {
-    double sqrtd = __builtin_sqrt(double(D));
+    double sqrtd = sqrt64(double(D));
     double nb = double(-b);
     double root = (nb - sqrtd) / double(a);
     if (reject_t(root, t_min, h.bt, idx, h.idx)) {

@@ -80,6 +80,43 @@ __device__ __forceinline__ uint32_t scan_v2(const Sph& s, float ox, float oy, fl
     return acc;
 }
 
+
+// V3: V2 with the next batch's scalar loads issued before the current batch is computed (4 pairs per batch)
+#define FILTER4(X, Y, Z, K)                                                                                             \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                     \
+        f2 b = __builtin_elementwise_fma(-Z[q], DZ, __builtin_elementwise_fma(-Y[q], DY, __builtin_elementwise_fma(-X[q], DX, OD))); \
+        f2 Q = __builtin_elementwise_fma(NA, K[q], MM);                                                                 \
+        Q = __builtin_elementwise_fma(WX, X[q], Q);                                                                     \
+        Q = __builtin_elementwise_fma(WY, Y[q], Q);                                                                     \
+        Q = __builtin_elementwise_fma(WZ, Z[q], Q);                                                                     \
+        f2 T = __builtin_elementwise_fma(b, b, Q);                                                                      \
+        m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x) & __float_as_uint(T.y), 31);                              \
+    }
+__device__ __forceinline__ uint32_t scan_v3(const Sph& s, float ox, float oy, float oz, float dx, float dy, float dz, float a) {
+    uint32_t acc = 0;
+    cf2p cx = (cf2p)(uintptr_t)s.cx, cy = (cf2p)(uintptr_t)s.cy, cz = (cf2p)(uintptr_t)s.cz, ck = (cf2p)(uintptr_t)s.r2;
+    float od = ox * dx + oy * dy + oz * dz, oo = ox * ox + oy * oy + oz * oz;
+    float M2 = 1e-3f * a - a * oo, w = 2.0f * a;
+    f2 DX = {dx, dx}, DY = {dy, dy}, DZ = {dz, dz}, OD = {od, od}, MM = {M2, M2}, NA = {-a, -a};
+    f2 WX = {w * ox, w * ox}, WY = {w * oy, w * oy}, WZ = {w * oz, w * oz};
+    f2 X[4], Y[4], Z[4], K[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { X[q] = cx[q]; Y[q] = cy[q]; Z[q] = cz[q]; K[q] = ck[q]; }
+    uint32_t m = 0;
+    for (int j0 = 4; j0 < NS / 2; j0 += 4) {
+        f2 Xn[4], Yn[4], Zn[4], Kn[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { Xn[q] = cx[j0 + q]; Yn[q] = cy[j0 + q]; Zn[q] = cz[j0 + q]; Kn[q] = ck[j0 + q]; }
+        FILTER4(X, Y, Z, K)
+        if ((j0 & 28) == 0) { acc ^= m * 2654435761u + (acc >> 3); m = 0; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { X[q] = Xn[q]; Y[q] = Yn[q]; Z[q] = Zn[q]; K[q] = Kn[q]; }
+    }
+    FILTER4(X, Y, Z, K)
+    acc ^= m * 2654435761u + (acc >> 3);
+    return acc;
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void k(const float* __restrict__ pcx, const float* __restrict__ pcy, const float* __restrict__ pcz, const float* __restrict__ pr2, const float* __restrict__ rays, uint32_t* __restrict__ out, long long* __restrict__ cyc) {
     extern __shared__ float lds_dummy[];
@@ -91,7 +128,7 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ pcx, const fl
     long long t0 = __builtin_amdgcn_s_memtime(); long long r0 = __builtin_amdgcn_s_memrealtime();
     for (int r = 0; r < REPS; ++r) {
         float a = dx * dx + dy * dy + dz * dz;
-        uint32_t m = V == 0 ? scan_v0(s, ox, oy, oz, dx, dy, dz, a) : V == 1 ? scan_v1(s, ox, oy, oz, dx, dy, dz, a) : scan_v2(s, ox, oy, oz, dx, dy, dz, a);
+        uint32_t m = V == 0 ? scan_v0(s, ox, oy, oz, dx, dy, dz, a) : V == 1 ? scan_v1(s, ox, oy, oz, dx, dy, dz, a) : V == 2 ? scan_v2(s, ox, oy, oz, dx, dy, dz, a) : scan_v3(s, ox, oy, oz, dx, dy, dz, a);
         acc ^= m;
         ox += 0.25f * float(m & 3u) - 0.3f;   // perturb the ray so that scans differ
         dz -= 0.001f * float((m >> 5) & 3u);
@@ -109,20 +146,20 @@ int main() {
     int bpc = getenv("BPC") ? atoi(getenv("BPC")) : 4; int grid = 256 * bpc, nthreads = grid * 256; size_t lds = 160 * 1024 / bpc; printf("blocks/CU %d lds %zu\n", bpc, lds);
     std::vector<float> rays(nthreads * 6);
     for (int i = 0; i < nthreads; ++i) { rays[6*i] = 13; rays[6*i+1] = 2; rays[6*i+2] = 3; rays[6*i+3] = -13 + 4*rnd(); rays[6*i+4] = -2 + rnd(); rays[6*i+5] = -3 + 4*rnd(); }
-    float *dcx, *dcy, *dcz, *dr2, *drays; uint32_t* dout[3]; long long* dcyc;
+    float *dcx, *dcy, *dcz, *dr2, *drays; uint32_t* dout[4]; long long* dcyc;
     hipMalloc(&dcx, NS*4); hipMalloc(&dcy, NS*4); hipMalloc(&dcz, NS*4); hipMalloc(&dr2, NS*4); hipMalloc(&drays, rays.size()*4);
-    hipMalloc(&dout[0], nthreads*4); hipMalloc(&dout[1], nthreads*4); hipMalloc(&dout[2], nthreads*4); hipMalloc(&dcyc, 32);
+    hipMalloc(&dout[0], nthreads*4); hipMalloc(&dout[1], nthreads*4); hipMalloc(&dout[2], nthreads*4); hipMalloc(&dout[3], nthreads*4); hipMalloc(&dcyc, 32);
     hipMemcpy(dcx, cx.data(), NS*4, hipMemcpyHostToDevice); hipMemcpy(dcy, cy.data(), NS*4, hipMemcpyHostToDevice);
     hipMemcpy(dcz, cz.data(), NS*4, hipMemcpyHostToDevice); hipMemcpy(dr2, r2.data(), NS*4, hipMemcpyHostToDevice);
     hipMemcpy(drays, rays.data(), rays.size()*4, hipMemcpyHostToDevice);
     Sph s{dcx, dcy, dcz, dr2};
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    std::vector<uint32_t> h[3];
-    for (int v = 0; v < 3; ++v) {
+    std::vector<uint32_t> h[4];
+    for (int v = 0; v < 4; ++v) {
         float ms = 0;
         for (int it = 0; it < 3; ++it) {
             hipEventRecord(e0);
-            if (v == 0) k<0><<<grid, 256, lds>>>(dcx, dcy, dcz, dr2, drays, dout[v], dcyc); else if (v == 1) k<1><<<grid, 256, lds>>>(dcx, dcy, dcz, dr2, drays, dout[v], dcyc); else k<2><<<grid, 256, lds>>>(dcx, dcy, dcz, dr2, drays, dout[v], dcyc);
+            if (v == 0) k<0><<<grid, 256, lds>>>(dcx, dcy, dcz, dr2, drays, dout[v], dcyc); else if (v == 1) k<1><<<grid, 256, lds>>>(dcx, dcy, dcz, dr2, drays, dout[v], dcyc); else if (v == 2) k<2><<<grid, 256, lds>>>(dcx, dcy, dcz, dr2, drays, dout[v], dcyc); else k<3><<<grid, 256, lds>>>(dcx, dcy, dcz, dr2, drays, dout[v], dcyc);
             hipEventRecord(e1); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1);
         }
