@@ -218,7 +218,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     const FilterGroup& tg = sc.tg;
     const int n_words = group_words(tg);
     if (n_words == 0) return;
-    const FilterRay fr = filter_ray(tg, r.o, r.d, r.dl2, __builtin_amdgcn_rcpf(r.dl2));
+    const FilterRay fr = filter_ray(tg, r.o, r.d, r.dl2, __builtin_amdgcn_rcpf(r.dl2), t_min >= 0.0);
     for (int w0 = 0; w0 < n_words; w0 += kMaskWords) {
         const int nw = n_words - w0 < kMaskWords ? n_words - w0 : kMaskWords;
         const uint32_t summary = filter_words(tg, fr, w0, nw, words);
@@ -792,12 +792,12 @@ void free_scene() {
 
 // Partition of one kind's items (bounding spheres: centre xyz + radius w; r2k: the radius^2 the filter
 // uses) into the exact group and the filter group of rt_scan.hpp, and the slot order of the arrays:
-// exact group in pairs, padded to whole 32-pair words; then the filter group in pairs, padded to a
-// multiple of 8 pairs. slot_item[slot] = item index, or -1 for a pad.
+// exact group in pairs, padded to whole 32-pair words; then the filter group in spatially compact
+// batches of 8 pairs with their bounding balls, padded to whole words. slot_item[slot] = item index, or -1 for a pad.
 struct GroupBuild {
     FilterGroup fg{};
     std::vector<int> slot_item;
-    std::vector<float> fx, fy, fz, fk;
+    std::vector<float> fx, fy, fz, fk, bnd;
 };
 void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k, float margin_k, bool finite, GroupBuild& out) {
     const int n = int(bound.size());
@@ -828,21 +828,66 @@ void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k
     fg.n_epairs = int((out.slot_item.size() + 1) / 2);
     fg.n_ewords = (fg.n_epairs + 31) / 32;
     out.slot_item.resize(size_t(fg.n_ewords) * 64, -1);
-    double cmax = 0, r2max = 0;
-    for (int i = 0; i < n; ++i) if (in_filter[i]) {
+    // filter group in spatially compact batches of 16 items: median splits along the widest axis, every
+    // part but the last a whole number of batches
+    std::vector<int> order;
+    for (int i = 0; i < n; ++i) if (in_filter[i]) order.push_back(i);
+    auto coord = [&](int i, int k) { return k == 0 ? bound[i].x : (k == 1 ? bound[i].y : bound[i].z); };
+    std::vector<std::pair<int, int>> todo;
+    todo.push_back({0, int(order.size())});
+    while (!todo.empty()) {
+        const int lo = todo.back().first, hi = todo.back().second;
+        todo.pop_back();
+        if (hi - lo <= 16) continue;
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int q = lo; q < hi; ++q) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], coord(order[q], k)); mx[k] = std::max(mx[k], coord(order[q], k)); }
+        int ax = 0;
+        for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
+        const int nb = (hi - lo + 15) / 16, mid = lo + 16 * (nb / 2);
+        std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi, [&](int a, int b) {
+            const float ca = coord(a, ax), cb = coord(b, ax);
+            return ca < cb || (ca == cb && a < b);
+        });
+        todo.push_back({lo, mid}); todo.push_back({mid, hi});
+    }
+    double cmax = 0, r2max = 0, rhomax = 0;
+    std::vector<double> rel;   // centre - g as the device sees it (FP32 values)
+    for (int i : order) {
         out.slot_item.push_back(i);
         const float rx = float(bound[i].x - gc[0]), ry = float(bound[i].y - gc[1]), rz = float(bound[i].z - gc[2]);
         const double c2 = double(rx) * rx + double(ry) * ry + double(rz) * rz;
         out.fx.push_back(rx); out.fy.push_back(ry); out.fz.push_back(rz); out.fk.push_back(float(c2 - double(r2k[i])));
+        rel.push_back(rx); rel.push_back(ry); rel.push_back(rz); rel.push_back(std::sqrt(double(r2k[i])));
         cmax = std::max(cmax, std::sqrt(c2)); r2max = std::max(r2max, double(r2k[i]));
     }
-    while (out.fx.size() % 16 != 0) {   // pads: k huge, never flagged
+    while (out.fx.size() % 64 != 0) {   // pads to whole words: k huge, never flagged
         out.fx.push_back(0.0f); out.fy.push_back(0.0f); out.fz.push_back(0.0f); out.fk.push_back(3.0e38f);
         out.slot_item.push_back(-1);
     }
     fg.n_fpairs = int(out.fx.size() / 2);
+    // ball of every batch: centre = middle of the centres' box, rho = max |centre_i - C| + r_i, rounded up
+    const int n_fwords = fg.n_fpairs / 32, n_items = int(order.size());
+    out.bnd.assign(size_t(n_fwords) * 20, 0.0f);
+    for (int b = 0; b < n_fwords * 4; ++b) {
+        float* w = &out.bnd[size_t(b / 4) * 20];
+        const int h = b % 4, i0 = b * 16, i1 = std::min(n_items, i0 + 16);
+        if (i0 >= i1) { w[12 + h] = 3.0e38f; continue; }
+        double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+        for (int i = i0; i < i1; ++i) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], rel[4 * i + k]); mx[k] = std::max(mx[k], rel[4 * i + k]); }
+        const float C[3] = {float(0.5 * (mn[0] + mx[0])), float(0.5 * (mn[1] + mx[1])), float(0.5 * (mn[2] + mx[2]))};
+        double rho = 0;
+        for (int i = i0; i < i1; ++i) {
+            const double dx = rel[4 * i] - C[0], dy = rel[4 * i + 1] - C[1], dz = rel[4 * i + 2] - C[2];
+            rho = std::max(rho, std::sqrt(dx * dx + dy * dy + dz * dz) + rel[4 * i + 3]);
+        }
+        const float rf = float(rho * 1.000001) + 1.0e-30f;
+        const double C2 = double(C[0]) * C[0] + double(C[1]) * C[1] + double(C[2]) * C[2];
+        w[h] = C[0]; w[4 + h] = C[1]; w[8 + h] = C[2]; w[12 + h] = float(C2 - double(rf) * rf); w[16 + h] = 2.0f * rf;
+        cmax = std::max(cmax, std::sqrt(C2)); rhomax = std::max(rhomax, double(rf));
+    }
     fg.gx = float(gc[0]); fg.gy = float(gc[1]); fg.gz = float(gc[2]);
     fg.cmax = float(cmax * 1.000001) + 1.0e-30f; fg.r2max = float(r2max * 1.000001);
+    fg.rhomax = float(rhomax * 1.000001);
     fg.margin_k = margin_k;
 }
 
@@ -1089,8 +1134,9 @@ int rt_upload_scene(const RtScene* s) {
     if (upload(mk, &ds.mat_kind) || upload(mrgb, &ds.mat_rgb) || upload(mf, &ds.mat_fuzz) || upload(mir, &ds.mat_ir) ||
         upload(minv, &ds.mat_inv_ir)) return 1;
     if (upload(sgb.fx, &sgb.fg.fx) || upload(sgb.fy, &sgb.fg.fy) || upload(sgb.fz, &sgb.fg.fz) || upload(sgb.fk, &sgb.fg.fk) ||
-        upload(fq, &sgb.fg.fq)) return 1;
-    if (upload(tgb.fx, &tgb.fg.fx) || upload(tgb.fy, &tgb.fg.fy) || upload(tgb.fz, &tgb.fg.fz) || upload(tgb.fk, &tgb.fg.fk)) return 1;
+        upload(sgb.bnd, &sgb.fg.bnd) || upload(fq, &sgb.fg.fq)) return 1;
+    if (upload(tgb.fx, &tgb.fg.fx) || upload(tgb.fy, &tgb.fg.fy) || upload(tgb.fz, &tgb.fg.fz) || upload(tgb.fk, &tgb.fg.fk) ||
+        upload(tgb.bnd, &tgb.fg.bnd)) return 1;
     tgb.fg.fq = nullptr;
     ds.sg = sgb.fg; ds.tg = tgb.fg; ds.fast_ok = finite ? 1 : 0;
     ds.light_kind = s->light_kind;

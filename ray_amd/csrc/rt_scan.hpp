@@ -14,6 +14,12 @@
 //     for the candidate that survives, or when two candidates' bounds overlap (ties included).
 // Spheres that are huge or far from the rest (the ground sphere) would blow up the filter margin of
 // every ray; rt_upload_scene puts them in the "exact group", whose pairs are always flagged.
+//  0. BATCH BOUNDS: the filter group is stored in spatially compact batches of 8 pairs (16 items), each
+//     with a bounding ball. The same packed test, on the ball widened by the ray's filter margin, tells
+//     per lane whether the line can come near any item of the batch, and, for t_min >= 0, whether
+//     the whole ball lies behind the ray's origin. A batch that no lane of the wave needs is not
+//     filtered at all (wave-uniform branch); a lane that does not need it gets no flags from it.
+//     Still brute force in the contract's sense: no item that the reference could hit is ever dropped.
 #pragma once
 #include "rt_device.hpp"
 
@@ -35,7 +41,7 @@ constexpr float kMaxCoord = 1.0e6f, kMinA = 1.0e-12f, kMaxA = 3.0e12f;
 // One filter group (the spheres, or the triangles through their bounding spheres, ray_amd_tri.h).
 // Pair index space: words [0, n_ewords) hold the exact group (n_epairs real pairs, always flagged, the
 // rest of the last word unused), words from n_ewords on hold the filter group (n_fpairs pairs, a
-// multiple of 8). Item slot 2*pair + h of the kind's arrays belongs to pair `pair`.
+// multiple of 32: whole words of 4 batches). Item slot 2*pair + h of the kind's arrays belongs to pair `pair`.
 struct FilterGroup {
     int n_epairs, n_ewords;
     int n_fpairs;
@@ -44,8 +50,11 @@ struct FilterGroup {
     const float* __restrict__ fz;
     const float* __restrict__ fk;    // [2 n_fpairs] |centre - g|^2 - r^2                   (pads: 3e38)
     const float4* __restrict__ fq;   // spheres only: [2 * all pairs] per pair (cx0,cx1,cy0,cy1), (cz0,cz1,r2_0,r2_1); pads NaN
+    const float* __restrict__ bnd;   // [20 per filter word] batch balls of the word's 4 batches: x0..x3, y0..y3, z0..z3 (centre - g),
+                                     // k0..k3 (|centre - g|^2 - rho^2), 2 rho 0..3; empty batch: k = 3e38
     float gx, gy, gz;                // reference point of the filter group
-    float cmax, r2max;               // max |centre - g| (rounded up), max r^2 over the filter group
+    float cmax, r2max;               // max |centre - g| over items and balls (rounded up), max r^2 over the filter group
+    float rhomax;                    // max ball radius rho (rounded up)
     float margin_k;                  // M = margin_k * a * (S^2 + So^2 + r2max)
 };
 constexpr float kMarginKTri = 160.0f * 5.9604644775390625e-08f;   // + the FP32 hit point's rounding (ray_amd_tri.h)
@@ -150,13 +159,15 @@ RT_DEV bool ray_in_fast_range(V3 o, V3 d, float a) {
            a >= kMinA && a <= kMaxA;
 }
 
-// Filter constants of one ray for one group (DESIGN.md "sphere filter").
+// Filter constants of one ray for one group (DESIGN.md "sphere filter", "batch bounds").
 struct FilterRay {
     f2 DX, DY, DZ, OD, MM, NA, WX, WY, WZ;
+    f2 MB, AM, SE;   // level 0: margin term, a * m, -(s a + margin) (SE = -3e38: no behind test)
 };
-__device__ __forceinline__ FilterRay filter_ray(const FilterGroup& fg, V3 o, V3 d, float a, float ia) {
+// behind_ok: t_min >= 0, so a batch whose ball lies wholly behind the origin cannot hold a hit
+__device__ __forceinline__ FilterRay filter_ray(const FilterGroup& fg, V3 o, V3 d, float a, float ia, bool behind_ok) {
     if (fg.n_fpairs == 0) {   // wave-uniform: only always-flagged pairs, the constants are not read
-        FilterRay z; z.DX = z.DY = z.DZ = f2{d.x, d.y}; z.OD = z.MM = z.NA = z.WX = z.WY = z.WZ = f2{0.0f, 0.0f};
+        FilterRay z; z.OD = z.MM = z.NA = z.WX = z.WY = z.WZ = z.MB = z.AM = z.SE = f2{0.0f, 0.0f};
         z.DX = f2{d.x, d.x}; z.DY = f2{d.y, d.y}; z.DZ = f2{d.z, d.z};
         return z;
     }
@@ -167,19 +178,27 @@ __device__ __forceinline__ FilterRay filter_ray(const FilterGroup& fg, V3 o, V3 
     float oo = __builtin_fmaf(op.z, op.z, __builtin_fmaf(op.y, op.y, op.x * op.x));
     float S = __builtin_amdgcn_sqrtf(oo) * 1.001f + fg.cmax;
     float So = __builtin_amdgcn_sqrtf(length_squared(orel)) * 1.001f + fg.cmax;
-    float M = fg.margin_k * a * (S * S + So * So + fg.r2max);
+    float SS = S * S + So * So;
+    float M = fg.margin_k * a * (SS + fg.r2max);
     float m2 = M - a * oo, wa = 2.0f * a;
+    // level 0: a flagged item's centre is within r + m of the line, m = sqrt(M / a); the ball test runs with radius rho + m
+    float m = __builtin_amdgcn_sqrtf(M * ia) * 1.001f + 1.0e-30f;
+    float Rm = fg.rhomax + m;
+    float Mb = fg.margin_k * a * (SS + Rm * Rm);
+    float am = a * m;
+    float mb = (Mb - a * oo) + am * m;
+    float se = behind_ok ? -(s * a + __builtin_amdgcn_sqrtf(Mb) * 1.001f) : -3.0e38f;
     FilterRay fr;
     fr.DX = f2{d.x, d.x}; fr.DY = f2{d.y, d.y}; fr.DZ = f2{d.z, d.z}; fr.OD = f2{od, od}; fr.MM = f2{m2, m2}; fr.NA = f2{-a, -a};
     fr.WX = f2{wa * op.x, wa * op.x}; fr.WY = f2{wa * op.y, wa * op.y}; fr.WZ = f2{wa * op.z, wa * op.z};
+    fr.MB = f2{mb, mb}; fr.AM = f2{am, am}; fr.SE = f2{se, se};
     return fr;
 }
 
-// Level 1 for words [w0, w0 + nw) of a group: one flag bit per pair (pair p of a word <-> bit 31 - p),
+// Level 0 + 1 for words [w0, w0 + nw) of a group: one flag bit per pair (pair p of a word <-> bit 31 - p),
 // words to this thread's LDS column; returns the mask of non-empty words.
 __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const FilterRay& fr, int w0, int nw, uint32_t* words) {
     cf2p fx = RT_CONST_F2(fg.fx), fy = RT_CONST_F2(fg.fy), fz = RT_CONST_F2(fg.fz), fk = RT_CONST_F2(fg.fk);
-    const int n_fbatches = fg.n_fpairs >> 3;                  // 8 pairs each
     uint32_t summary = 0;
     for (int wi = 0; wi < nw; ++wi) {
         const int gw = w0 + wi;
@@ -188,24 +207,51 @@ __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const Fi
             const int real = fg.n_epairs - gw * 32;
             flagged = real >= 32 ? 0xffffffffu : ~(0xffffffffu >> real);
         } else {
-            int batch = (gw - fg.n_ewords) * 4;
-            const int nb = n_fbatches - batch < 4 ? n_fbatches - batch : 4;
-            uint32_t m = 0;
-            for (int bb = 0; bb < nb; ++bb, ++batch) {
+            const int fw = gw - fg.n_ewords;
+            // level 0: the word's 4 batch balls, two per packed operation. Sign bit of sk[b] set: this lane skips batch b.
+            cf2p bn = RT_CONST_F2(fg.bnd) + fw * 10;
+            uint32_t sk[4];
+            uint32_t act = 0;                                  // wave-uniform: batches that some lane needs
 #pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-                    const int j = batch * 8 + jj;
-                    f2 X = fx[j], Y = fy[j], Z = fz[j], K = fk[j];
-                    f2 bq = __builtin_elementwise_fma(-Z, fr.DZ, __builtin_elementwise_fma(-Y, fr.DY, __builtin_elementwise_fma(-X, fr.DX, fr.OD)));
-                    f2 Q = __builtin_elementwise_fma(fr.NA, K, fr.MM);
-                    Q = __builtin_elementwise_fma(fr.WX, X, Q);
-                    Q = __builtin_elementwise_fma(fr.WY, Y, Q);
-                    Q = __builtin_elementwise_fma(fr.WZ, Z, Q);
-                    f2 T = __builtin_elementwise_fma(bq, bq, Q);   // >= 0 (sign bit clear): flagged
-                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x) & __float_as_uint(T.y), 31);
+            for (int h = 0; h < 2; ++h) {
+                const f2 X = bn[h], Y = bn[2 + h], Z = bn[4 + h], K = bn[6 + h], R2 = bn[8 + h];
+                const f2 bq = __builtin_elementwise_fma(-Z, fr.DZ, __builtin_elementwise_fma(-Y, fr.DY, __builtin_elementwise_fma(-X, fr.DX, fr.OD)));
+                f2 Q = __builtin_elementwise_fma(fr.NA, K, fr.MB);
+                Q = __builtin_elementwise_fma(fr.AM, R2, Q);
+                Q = __builtin_elementwise_fma(fr.WX, X, Q);
+                Q = __builtin_elementwise_fma(fr.WY, Y, Q);
+                Q = __builtin_elementwise_fma(fr.WZ, Z, Q);
+                const f2 T = __builtin_elementwise_fma(bq, bq, Q);     // < 0: the line misses the widened ball
+                const f2 e = bq + fr.SE;                                // > 0: the ball's centre is behind the origin by the margin
+                const f2 V = __builtin_elementwise_fma(e, e, -T);       // >= 0 with e >= 0: the ball ends before the origin
+                sk[2 * h] = __float_as_uint(T.x) | ~(__float_as_uint(e.x) | __float_as_uint(V.x));
+                sk[2 * h + 1] = __float_as_uint(T.y) | ~(__float_as_uint(e.y) | __float_as_uint(V.y));
+                act |= (__ballot(int(sk[2 * h]) >= 0) != 0ull ? 1u : 0u) << (2 * h);
+                act |= (__ballot(int(sk[2 * h + 1]) >= 0) != 0ull ? 1u : 0u) << (2 * h + 1);
+            }
+            uint32_t m = 0;                                    // bit set: pair NOT flagged
+            if (act == 0u) {
+                m = 0xffffffffu;
+            } else {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    if ((act >> bb & 1u) == 0u) { m = (m << 8) | 0xffu; continue; }
+                    const int batch = fw * 4 + bb;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int j = batch * 8 + jj;
+                        f2 X = fx[j], Y = fy[j], Z = fz[j], K = fk[j];
+                        f2 bq = __builtin_elementwise_fma(-Z, fr.DZ, __builtin_elementwise_fma(-Y, fr.DY, __builtin_elementwise_fma(-X, fr.DX, fr.OD)));
+                        f2 Q = __builtin_elementwise_fma(fr.NA, K, fr.MM);
+                        Q = __builtin_elementwise_fma(fr.WX, X, Q);
+                        Q = __builtin_elementwise_fma(fr.WY, Y, Q);
+                        Q = __builtin_elementwise_fma(fr.WZ, Z, Q);
+                        f2 T = __builtin_elementwise_fma(bq, bq, Q);   // >= 0 (sign bit clear): flagged
+                        m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x) & __float_as_uint(T.y), 31);
+                    }
+                    m |= uint32_t(int(sk[bb]) >> 31) & 0xffu;          // this lane does not need the batch
                 }
             }
-            if (nb < 4) m = (m << (32 - 8 * nb)) | (0xffffffffu >> (8 * nb));
             flagged = ~m;
         }
         words[wi * kScanBlock] = flagged;
@@ -233,7 +279,7 @@ __device__ __forceinline__ void walk_flagged(uint32_t summary, int w0, const uin
     }
 }
 
-__device__ __forceinline__ int group_words(const FilterGroup& fg) { return fg.n_ewords + (((fg.n_fpairs >> 3) + 3) >> 2); }
+__device__ __forceinline__ int group_words(const FilterGroup& fg) { return fg.n_ewords + (fg.n_fpairs >> 5); }
 
 // Spheres of one ray (o, d, a = d.lengthSquared() as Ray.h:8 caches it). `words` is this thread's
 // column of the block's flag-word array in LDS (stride kScanBlock). sph_prim: flattened primitive
@@ -244,7 +290,7 @@ __device__ __forceinline__ void scan_spheres(const FilterGroup& sg, const int* _
     if (n_words == 0) return;
     const float tmin_lo = __double2float_rd(t_min), tmin_hi = __double2float_ru(t_min);
     const float ia = __builtin_amdgcn_rcpf(a);
-    const FilterRay fr = filter_ray(sg, o, d, a, ia);
+    const FilterRay fr = filter_ray(sg, o, d, a, ia, t_min >= 0.0);
     const f2 OX = {o.x, o.x}, OY = {o.y, o.y}, OZ = {o.z, o.z}, AA = {a, a};
     for (int w0 = 0; w0 < n_words; w0 += kMaskWords) {
         const int nw = n_words - w0 < kMaskWords ? n_words - w0 : kMaskWords;
