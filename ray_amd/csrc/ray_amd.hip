@@ -216,22 +216,25 @@ __device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const R
 // tri_t on the flagged pairs. h is exact on entry and on return.
 __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r, double t_min, Hit& h, uint32_t* words RT_STAMP_PARAM) {
     const FilterGroup& tg = sc.tg;
-    const int n_words = group_words(tg);
-    if (n_words == 0) return;
-    const FilterRay fr = filter_ray(tg, r.o, r.d, r.dl2, __builtin_amdgcn_rcpf(r.dl2), t_min >= 0.0);
-    for (int w0 = 0; w0 < n_words; w0 += kMaskWords) {
-        const int nw = n_words - w0 < kMaskWords ? n_words - w0 : kMaskWords;
-        const uint32_t summary = filter_words(tg, fr, w0, nw, words);
-        RT_STAMP(2);
-        walk_flagged(summary, w0, words, [&](int pair) {
+    if (tg.n_epairs == 0 && tg.n_fpairs == 0) return;
+    auto visit = [&](int pair) {
 #pragma unroll 1
-            for (int hh = 0; hh < 4; ++hh) {   // two items of up to two triangles each
-                const int slot = 4 * pair + hh;
-                const int idx = sc.tri_prim[slot];
-                double t;
-                if (idx >= 0 && tri_t(r, sc.tri + 16 * slot, t_min, h.t, idx, h.prim, &t)) { h.t = t; h.prim = idx; }
-            }
-        } RT_STAMP_ARG);
+        for (int hh = 0; hh < 4; ++hh) {   // two items of up to two triangles each
+            const int slot = 4 * pair + hh;
+            const int idx = sc.tri_prim[slot];
+            double t;
+            if (idx >= 0 && tri_t(r, sc.tri + 16 * slot, t_min, h.t, idx, h.prim, &t)) { h.t = t; h.prim = idx; }
+        }
+    };
+    for (int p = 0; p < tg.n_epairs; ++p) visit(p);
+    if (tg.n_fpairs == 0) return;
+    const FilterRay fr = filter_ray(tg, r.o, r.d, r.dl2, __builtin_amdgcn_rcpf(r.dl2), t_min);
+    const int n_fwords = tg.n_fpairs >> 5;
+    for (int fw0 = 0; fw0 < n_fwords; fw0 += kMaskWords) {
+        const int nw = n_fwords - fw0 < kMaskWords ? n_fwords - fw0 : kMaskWords;
+        const uint32_t summary = filter_words(tg, fr, __double2float_ru(h.t), fw0, nw, words RT_STAMP_ARG);
+        RT_STAMP(2);
+        walk_flagged(summary, tg.n_ewords + fw0, words, visit RT_STAMP_ARG);
         RT_STAMP(3);
     }
 }
@@ -850,7 +853,7 @@ void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k
         });
         todo.push_back({lo, mid}); todo.push_back({mid, hi});
     }
-    double cmax = 0, r2max = 0, rhomax = 0;
+    double cmax = 0, r2max = 0;
     std::vector<double> rel;   // centre - g as the device sees it (FP32 values)
     for (int i : order) {
         out.slot_item.push_back(i);
@@ -865,29 +868,24 @@ void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k
         out.slot_item.push_back(-1);
     }
     fg.n_fpairs = int(out.fx.size() / 2);
-    // ball of every batch: centre = middle of the centres' box, rho = max |centre_i - C| + r_i, rounded up
+    // box of every batch around its items' spheres (radius: the one the filter uses), relative to g, rounded outwards
     const int n_fwords = fg.n_fpairs / 32, n_items = int(order.size());
-    out.bnd.assign(size_t(n_fwords) * 20, 0.0f);
-    for (int b = 0; b < n_fwords * 4; ++b) {
-        float* w = &out.bnd[size_t(b / 4) * 20];
+    fg.n_fbatches = (n_items + 15) / 16;
+    out.bnd.assign(size_t(n_fwords) * 24, 0.0f);
+    auto down = [](double v) { float f = float(v); return double(f) > v ? std::nextafterf(f, -INFINITY) : f; };
+    auto up = [](double v) { float f = float(v); return double(f) < v ? std::nextafterf(f, INFINITY) : f; };
+    for (int b = 0; b < fg.n_fbatches; ++b) {
+        float* w = &out.bnd[size_t(b / 4) * 24];
         const int h = b % 4, i0 = b * 16, i1 = std::min(n_items, i0 + 16);
-        if (i0 >= i1) { w[12 + h] = 3.0e38f; continue; }
         double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-        for (int i = i0; i < i1; ++i) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], rel[4 * i + k]); mx[k] = std::max(mx[k], rel[4 * i + k]); }
-        const float C[3] = {float(0.5 * (mn[0] + mx[0])), float(0.5 * (mn[1] + mx[1])), float(0.5 * (mn[2] + mx[2]))};
-        double rho = 0;
-        for (int i = i0; i < i1; ++i) {
-            const double dx = rel[4 * i] - C[0], dy = rel[4 * i + 1] - C[1], dz = rel[4 * i + 2] - C[2];
-            rho = std::max(rho, std::sqrt(dx * dx + dy * dy + dz * dz) + rel[4 * i + 3]);
+        for (int i = i0; i < i1; ++i) for (int k = 0; k < 3; ++k) {
+            const double rr = rel[4 * i + 3] * 1.000001;
+            mn[k] = std::min(mn[k], rel[4 * i + k] - rr); mx[k] = std::max(mx[k], rel[4 * i + k] + rr);
         }
-        const float rf = float(rho * 1.000001) + 1.0e-30f;
-        const double C2 = double(C[0]) * C[0] + double(C[1]) * C[1] + double(C[2]) * C[2];
-        w[h] = C[0]; w[4 + h] = C[1]; w[8 + h] = C[2]; w[12 + h] = float(C2 - double(rf) * rf); w[16 + h] = 2.0f * rf;
-        cmax = std::max(cmax, std::sqrt(C2)); rhomax = std::max(rhomax, double(rf));
+        for (int k = 0; k < 3; ++k) { w[4 * k + h] = down(mn[k]); w[12 + 4 * k + h] = up(mx[k]); }
     }
     fg.gx = float(gc[0]); fg.gy = float(gc[1]); fg.gz = float(gc[2]);
     fg.cmax = float(cmax * 1.000001) + 1.0e-30f; fg.r2max = float(r2max * 1.000001);
-    fg.rhomax = float(rhomax * 1.000001);
     fg.margin_k = margin_k;
 }
 

@@ -14,11 +14,12 @@
 //     for the candidate that survives, or when two candidates' bounds overlap (ties included).
 // Spheres that are huge or far from the rest (the ground sphere) would blow up the filter margin of
 // every ray; rt_upload_scene puts them in the "exact group", whose pairs are always flagged.
-//  0. BATCH BOUNDS: the filter group is stored in spatially compact batches of 8 pairs (16 items), each
-//     with a bounding ball. The same packed test, on the ball widened by the ray's filter margin, tells
-//     per lane whether the line can come near any item of the batch, and, for t_min >= 0, whether
-//     the whole ball lies behind the ray's origin. A batch that no lane of the wave needs is not
-//     filtered at all (wave-uniform branch); a lane that does not need it gets no flags from it.
+//  0. BATCH BOXES: the filter group is stored in spatially compact batches of 8 pairs (16 items), each
+//     with an axis-aligned box around its items. A slab test of the ray against the box, widened by the
+//     ray's filter margin, tells per lane whether the ray can come near any item of the batch inside
+//     [max(t_min, 0), best t so far]. A batch that no lane of the wave needs is not filtered at all
+//     (wave-uniform branch); a lane that does not need it gets no flags from it. The exact group is
+//     visited first, so the ground's hit already bounds t when the boxes are tested.
 //     Still brute force in the contract's sense: no item that the reference could hit is ever dropped.
 #pragma once
 #include "rt_device.hpp"
@@ -50,11 +51,11 @@ struct FilterGroup {
     const float* __restrict__ fz;
     const float* __restrict__ fk;    // [2 n_fpairs] |centre - g|^2 - r^2                   (pads: 3e38)
     const float4* __restrict__ fq;   // spheres only: [2 * all pairs] per pair (cx0,cx1,cy0,cy1), (cz0,cz1,r2_0,r2_1); pads NaN
-    const float* __restrict__ bnd;   // [20 per filter word] batch balls of the word's 4 batches: x0..x3, y0..y3, z0..z3 (centre - g),
-                                     // k0..k3 (|centre - g|^2 - rho^2), 2 rho 0..3; empty batch: k = 3e38
+    const float* __restrict__ bnd;   // [24 per filter word] boxes of the word's 4 batches, relative to g, item radii included:
+                                     // lo x0..x3, lo y0..y3, lo z0..z3, hi x0..x3, hi y0..y3, hi z0..z3
+    int n_fbatches;                  // batches that hold items (the rest of the last word is padding)
     float gx, gy, gz;                // reference point of the filter group
-    float cmax, r2max;               // max |centre - g| over items and balls (rounded up), max r^2 over the filter group
-    float rhomax;                    // max ball radius rho (rounded up)
+    float cmax, r2max;               // max |centre - g| (rounded up), max r^2 over the filter group
     float margin_k;                  // M = margin_k * a * (S^2 + So^2 + r2max)
 };
 constexpr float kMarginKTri = 160.0f * 5.9604644775390625e-08f;   // + the FP32 hit point's rounding (ray_amd_tri.h)
@@ -63,7 +64,7 @@ constexpr float kMarginKTri = 160.0f * 5.9604644775390625e-08f;   // + the FP32 
 // and wave-level pass counts of the divergent loops. Never compiled into the product library.
 #ifdef RT_STAMPS
 struct Stamps {
-    unsigned long long t[8];     // 0 assign+new sample, 1 -, 2 filter, 3 candidate walk, 4 rect+tri, 5 shade, 6 unwind+store, 7 other
+    unsigned long long t[8];     // 0 assign+new sample, 1 (count, not cycles) batches filtered, 2 filter, 3 candidate walk, 4 rect+tri, 5 shade, 6 unwind+store, 7 other
     unsigned long long last;
     unsigned int cnt[4];         // 0 walk passes and 3 scans (first active lane only); 1 flagged sphere pairs and 2 sphere candidates (every lane)
 };
@@ -71,9 +72,11 @@ struct Stamps {
 #define RT_COUNT(i) do { if ((__ffsll((long long)__ballot(1)) - 1) == int(threadIdx.x & 63)) ++stp.cnt[i]; } while (0)
 #define RT_COUNT_LANES(i) do { ++stp.cnt[i]; } while (0)
 #define RT_STAMP_PARAM , Stamps& stp
+#define RT_BATCHES(act) do { stp.t[1] += __builtin_popcount(act); } while (0)
 #define RT_STAMP_ARG , stp
 #else
 #define RT_COUNT_LANES(i) do {} while (0)
+#define RT_BATCHES(act) do {} while (0)
 #define RT_STAMP(i) do {} while (0)
 #define RT_COUNT(i) do {} while (0)
 #define RT_STAMP_PARAM
@@ -159,17 +162,61 @@ RT_DEV bool ray_in_fast_range(V3 o, V3 d, float a) {
            a >= kMinA && a <= kMaxA;
 }
 
-// Filter constants of one ray for one group (DESIGN.md "sphere filter", "batch bounds").
+// v_pk_fma_f32 with one half of a register pair as the multiplier of both results (op_sel), so that two
+// different per-ray constants share a pair instead of each being duplicated: r = c[SC] * x + a (cv) or
+// r = c[SC] * x + a[SA] (cc). x: wave-uniform data in an SGPR pair.
+template <int SC>
+__device__ __forceinline__ f2 pk_fma_cv(f2 c, f2 x, f2 a) {
+    f2 r;
+    if (SC == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(c), "s"(x), "v"(a));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(c), "s"(x), "v"(a));
+    return r;
+}
+template <int SC, int SA>
+__device__ __forceinline__ f2 pk_fma_cc(f2 c, f2 x, f2 a) {
+    f2 r;
+    if (SC == 0 && SA == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(c), "s"(x), "v"(a));
+    else if (SC == 0 && SA == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(c), "s"(x), "v"(a));
+    else if (SC == 1 && SA == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(c), "s"(x), "v"(a));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(c), "s"(x), "v"(a));
+    return r;
+}
+
+// min / max on results of the above (asm: the compiler would first canonicalise values it did not compute itself)
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// the same for v_pk_mul_f32 / v_pk_add_f32 with per-lane data x: r = c[SC] * x, r = c[SC] - x
+template <int SC>
+__device__ __forceinline__ f2 pk_mul_c(f2 c, f2 x) {
+    f2 r;
+    if (SC == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(c), "v"(x));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(r) : "v"(c), "v"(x));
+    return r;
+}
+template <int SC>
+__device__ __forceinline__ f2 pk_sub_c(f2 c, f2 x) {
+    f2 r;
+    if (SC == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(c), "v"(x));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(c), "v"(x));
+    return r;
+}
+
+// Filter constants of one ray for one group (DESIGN.md "sphere filter", "batch boxes").
 struct FilterRay {
-    f2 DX, DY, DZ, OD, MM, NA, WX, WY, WZ;
-    f2 MB, AM, SE;   // level 0: margin term, a * m, -(s a + margin) (SE = -3e38: no behind test)
+    // level 1: T = bq^2 + Q, bq = od - c.d, Q = (M - a |op|^2) - a k + 2 a op.c
+    f2 D01, D2O, NAM, W01, W2;   // (-d.x, -d.y), (-d.z, od), (-a, M - a |op|^2), (2a op.x, 2a op.y), (2a op.z, -)
+    // level 0: t = inv * plane + c per slab plane
+    f2 I01, I2, CX, CY, CZ;      // (inv.x, inv.y), (inv.z, -), (c_lo, c_hi) per axis
+    float t_lo;
 };
-// behind_ok: t_min >= 0, so a batch whose ball lies wholly behind the origin cannot hold a hit
-__device__ __forceinline__ FilterRay filter_ray(const FilterGroup& fg, V3 o, V3 d, float a, float ia, bool behind_ok) {
+__device__ __forceinline__ FilterRay filter_ray(const FilterGroup& fg, V3 o, V3 d, float a, float ia, double t_min) {
+    FilterRay fr;
     if (fg.n_fpairs == 0) {   // wave-uniform: only always-flagged pairs, the constants are not read
-        FilterRay z; z.OD = z.MM = z.NA = z.WX = z.WY = z.WZ = z.MB = z.AM = z.SE = f2{0.0f, 0.0f};
-        z.DX = f2{d.x, d.x}; z.DY = f2{d.y, d.y}; z.DZ = f2{d.z, d.z};
-        return z;
+        fr.D01 = fr.D2O = fr.NAM = fr.W01 = fr.W2 = fr.I01 = fr.I2 = fr.CX = fr.CY = fr.CZ = f2{0.0f, 0.0f};
+        fr.t_lo = 0.0f;
+        return fr;
     }
     V3 orel = o - v3(fg.gx, fg.gy, fg.gz);
     float s = -(orel.x * d.x + orel.y * d.y + orel.z * d.z) * ia;
@@ -178,82 +225,84 @@ __device__ __forceinline__ FilterRay filter_ray(const FilterGroup& fg, V3 o, V3 
     float oo = __builtin_fmaf(op.z, op.z, __builtin_fmaf(op.y, op.y, op.x * op.x));
     float S = __builtin_amdgcn_sqrtf(oo) * 1.001f + fg.cmax;
     float So = __builtin_amdgcn_sqrtf(length_squared(orel)) * 1.001f + fg.cmax;
-    float SS = S * S + So * So;
-    float M = fg.margin_k * a * (SS + fg.r2max);
+    float M = fg.margin_k * a * (S * S + So * So + fg.r2max);
     float m2 = M - a * oo, wa = 2.0f * a;
-    // level 0: a flagged item's centre is within r + m of the line, m = sqrt(M / a); the ball test runs with radius rho + m
-    float m = __builtin_amdgcn_sqrtf(M * ia) * 1.001f + 1.0e-30f;
-    float Rm = fg.rhomax + m;
-    float Mb = fg.margin_k * a * (SS + Rm * Rm);
-    float am = a * m;
-    float mb = (Mb - a * oo) + am * m;
-    float se = behind_ok ? -(s * a + __builtin_amdgcn_sqrtf(Mb) * 1.001f) : -3.0e38f;
-    FilterRay fr;
-    fr.DX = f2{d.x, d.x}; fr.DY = f2{d.y, d.y}; fr.DZ = f2{d.z, d.z}; fr.OD = f2{od, od}; fr.MM = f2{m2, m2}; fr.NA = f2{-a, -a};
-    fr.WX = f2{wa * op.x, wa * op.x}; fr.WY = f2{wa * op.y, wa * op.y}; fr.WZ = f2{wa * op.z, wa * op.z};
-    fr.MB = f2{mb, mb}; fr.AM = f2{am, am}; fr.SE = f2{se, se};
+    fr.D01 = f2{-d.x, -d.y}; fr.D2O = f2{-d.z, od}; fr.NAM = f2{-a, m2};
+    fr.W01 = f2{wa * op.x, wa * op.y}; fr.W2 = f2{wa * op.z, 0.0f};
+    // level 0 (DESIGN.md "batch boxes"): a flagged item's centre is within r + m of the line, m = sqrt(M / a); the
+    // boxes hold the items' radii and are widened by 1.01 m, which also covers the rounding of the slab
+    // arithmetic and the clamp of direction components below 1e-7 |d|
+    const float m = __builtin_amdgcn_sqrtf(M * ia) * 1.01f + 1.0e-30f;
+    const float dmin = 1.0e-7f * __builtin_amdgcn_sqrtf(a);
+    const float ix = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.x), dmin), d.x));
+    const float iy = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.y), dmin), d.y));
+    const float iz = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.z), dmin), d.z));
+    fr.I01 = f2{ix, iy}; fr.I2 = f2{iz, 0.0f};
+    fr.CX = f2{-(orel.x + m) * ix, -(orel.x - m) * ix};
+    fr.CY = f2{-(orel.y + m) * iy, -(orel.y - m) * iy};
+    fr.CZ = f2{-(orel.z + m) * iz, -(orel.z - m) * iz};
+    fr.t_lo = t_min >= 0.0 ? 0.0f : -__builtin_inff();
     return fr;
 }
 
-// Level 0 + 1 for words [w0, w0 + nw) of a group: one flag bit per pair (pair p of a word <-> bit 31 - p),
-// words to this thread's LDS column; returns the mask of non-empty words.
-__device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const FilterRay& fr, int w0, int nw, uint32_t* words) {
+// Level 0 + 1 for filter words [fw0, fw0 + nw) of a group: one flag bit per pair (pair p of a word <-> bit
+// 31 - p), words to this thread's LDS column; returns the mask of non-empty words. t_hi: upper bound of the
+// best t so far (boxes wholly beyond it are not needed).
+__device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const FilterRay& fr, float t_hi, int fw0, int nw, uint32_t* words RT_STAMP_PARAM) {
     cf2p fx = RT_CONST_F2(fg.fx), fy = RT_CONST_F2(fg.fy), fz = RT_CONST_F2(fg.fz), fk = RT_CONST_F2(fg.fk);
     uint32_t summary = 0;
     for (int wi = 0; wi < nw; ++wi) {
-        const int gw = w0 + wi;
-        uint32_t flagged;
-        if (gw < fg.n_ewords) {                                // exact group: every real pair
-            const int real = fg.n_epairs - gw * 32;
-            flagged = real >= 32 ? 0xffffffffu : ~(0xffffffffu >> real);
-        } else {
-            const int fw = gw - fg.n_ewords;
-            // level 0: the word's 4 batch balls, two per packed operation. Sign bit of sk[b] set: this lane skips batch b.
-            cf2p bn = RT_CONST_F2(fg.bnd) + fw * 10;
-            uint32_t sk[4];
-            uint32_t act = 0;                                  // wave-uniform: batches that some lane needs
+        const int fw = fw0 + wi;
+        // level 0: the word's 4 batch boxes, two per packed operation
+        cf2p bn = RT_CONST_F2(fg.bnd) + fw * 12;
+        bool nd[4];                                        // this lane needs batch b
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f2 X = bn[h], Y = bn[2 + h], Z = bn[4 + h], K = bn[6 + h], R2 = bn[8 + h];
-                const f2 bq = __builtin_elementwise_fma(-Z, fr.DZ, __builtin_elementwise_fma(-Y, fr.DY, __builtin_elementwise_fma(-X, fr.DX, fr.OD)));
-                f2 Q = __builtin_elementwise_fma(fr.NA, K, fr.MB);
-                Q = __builtin_elementwise_fma(fr.AM, R2, Q);
-                Q = __builtin_elementwise_fma(fr.WX, X, Q);
-                Q = __builtin_elementwise_fma(fr.WY, Y, Q);
-                Q = __builtin_elementwise_fma(fr.WZ, Z, Q);
-                const f2 T = __builtin_elementwise_fma(bq, bq, Q);     // < 0: the line misses the widened ball
-                const f2 e = bq + fr.SE;                                // > 0: the ball's centre is behind the origin by the margin
-                const f2 V = __builtin_elementwise_fma(e, e, -T);       // >= 0 with e >= 0: the ball ends before the origin
-                sk[2 * h] = __float_as_uint(T.x) | ~(__float_as_uint(e.x) | __float_as_uint(V.x));
-                sk[2 * h + 1] = __float_as_uint(T.y) | ~(__float_as_uint(e.y) | __float_as_uint(V.y));
-                act |= (__ballot(int(sk[2 * h]) >= 0) != 0ull ? 1u : 0u) << (2 * h);
-                act |= (__ballot(int(sk[2 * h + 1]) >= 0) != 0ull ? 1u : 0u) << (2 * h + 1);
+        for (int h = 0; h < 2; ++h) {
+            const f2 LX = bn[h], LY = bn[2 + h], LZ = bn[4 + h], HX = bn[6 + h], HY = bn[8 + h], HZ = bn[10 + h];
+            const f2 x1 = pk_fma_cc<0, 0>(fr.I01, LX, fr.CX), x2 = pk_fma_cc<0, 1>(fr.I01, HX, fr.CX);
+            const f2 y1 = pk_fma_cc<1, 0>(fr.I01, LY, fr.CY), y2 = pk_fma_cc<1, 1>(fr.I01, HY, fr.CY);
+            const f2 z1 = pk_fma_cc<0, 0>(fr.I2, LZ, fr.CZ), z2 = pk_fma_cc<0, 1>(fr.I2, HZ, fr.CZ);
+            {
+                const float tn = vmax3(vmin(x1.x, x2.x), vmin(y1.x, y2.x), vmin(z1.x, z2.x));
+                const float tf = vmin3(vmax(x1.x, x2.x), vmax(y1.x, y2.x), vmax(z1.x, z2.x));
+                nd[2 * h] = vmax(tn, fr.t_lo) <= vmin(tf, t_hi);
             }
-            uint32_t m = 0;                                    // bit set: pair NOT flagged
-            if (act == 0u) {
-                m = 0xffffffffu;
-            } else {
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) {
-                    if ((act >> bb & 1u) == 0u) { m = (m << 8) | 0xffu; continue; }
-                    const int batch = fw * 4 + bb;
-#pragma unroll
-                    for (int jj = 0; jj < 8; ++jj) {
-                        const int j = batch * 8 + jj;
-                        f2 X = fx[j], Y = fy[j], Z = fz[j], K = fk[j];
-                        f2 bq = __builtin_elementwise_fma(-Z, fr.DZ, __builtin_elementwise_fma(-Y, fr.DY, __builtin_elementwise_fma(-X, fr.DX, fr.OD)));
-                        f2 Q = __builtin_elementwise_fma(fr.NA, K, fr.MM);
-                        Q = __builtin_elementwise_fma(fr.WX, X, Q);
-                        Q = __builtin_elementwise_fma(fr.WY, Y, Q);
-                        Q = __builtin_elementwise_fma(fr.WZ, Z, Q);
-                        f2 T = __builtin_elementwise_fma(bq, bq, Q);   // >= 0 (sign bit clear): flagged
-                        m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x) & __float_as_uint(T.y), 31);
-                    }
-                    m |= uint32_t(int(sk[bb]) >> 31) & 0xffu;          // this lane does not need the batch
-                }
+            {
+                const float tn = vmax3(vmin(x1.y, x2.y), vmin(y1.y, y2.y), vmin(z1.y, z2.y));
+                const float tf = vmin3(vmax(x1.y, x2.y), vmax(y1.y, y2.y), vmax(z1.y, z2.y));
+                nd[2 * h + 1] = vmax(tn, fr.t_lo) <= vmin(tf, t_hi);
             }
-            flagged = ~m;
         }
+        const int real = fg.n_fbatches - fw * 4;               // padding batches hold no items
+        uint32_t act = 0;                                      // wave-uniform: batches that some lane needs
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) act |= (__ballot(nd[bb]) != 0ull && bb < real ? 1u : 0u) << bb;
+        RT_BATCHES(act);
+        uint32_t m = 0xffffffffu;                              // bit set: pair NOT flagged
+        if (act != 0u) {
+            m = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                if ((act >> bb & 1u) == 0u) { m = (m << 8) | 0xffu; continue; }
+                const int batch = fw * 4 + bb;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int j = batch * 8 + jj;
+                    const f2 X = fx[j], Y = fy[j], Z = fz[j], K = fk[j];
+                    f2 bq = pk_fma_cc<0, 1>(fr.D01, X, fr.D2O);
+                    bq = pk_fma_cv<1>(fr.D01, Y, bq);
+                    bq = pk_fma_cv<0>(fr.D2O, Z, bq);
+                    f2 Q = pk_fma_cc<0, 1>(fr.NAM, K, fr.NAM);
+                    Q = pk_fma_cv<0>(fr.W01, X, Q);
+                    Q = pk_fma_cv<1>(fr.W01, Y, Q);
+                    Q = pk_fma_cv<0>(fr.W2, Z, Q);
+                    const f2 T = __builtin_elementwise_fma(bq, bq, Q);   // >= 0 (sign bit clear): flagged
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x) & __float_as_uint(T.y), 31);
+                }
+                m |= nd[bb] ? 0u : 0xffu;     // this lane does not need the batch
+            }
+        }
+        const uint32_t flagged = ~m;
         words[wi * kScanBlock] = flagged;
         summary |= (flagged != 0u ? 1u : 0u) << wi;
     }
@@ -262,7 +311,7 @@ __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const Fi
 
 // Level 2 driver: each lane walks its own flagged pairs of the chunk and calls visit(pair).
 template <class Visit>
-__device__ __forceinline__ void walk_flagged(uint32_t summary, int w0, const uint32_t* words, Visit&& visit RT_STAMP_PARAM) {
+__device__ __forceinline__ void walk_flagged(uint32_t summary, int w0, const uint32_t* words, Visit&& visit RT_STAMP_PARAM) {   // w0: word index of the chunk in pair space
     uint32_t cur = 0;
     int wbase = 0;
     while (cur != 0u || summary != 0u) {
@@ -279,39 +328,44 @@ __device__ __forceinline__ void walk_flagged(uint32_t summary, int w0, const uin
     }
 }
 
-__device__ __forceinline__ int group_words(const FilterGroup& fg) { return fg.n_ewords + (fg.n_fpairs >> 5); }
-
 // Spheres of one ray (o, d, a = d.lengthSquared() as Ray.h:8 caches it). `words` is this thread's
 // column of the block's flag-word array in LDS (stride kScanBlock). sph_prim: flattened primitive
 // index per sphere slot (-1 for pads). Requires ray_in_fast_range and a finite scene. On return h is exact.
 __device__ __forceinline__ void scan_spheres(const FilterGroup& sg, const int* __restrict__ sph_prim, V3 o, V3 d, float a, double t_min,
                                              double t_max, HitState& h, uint32_t* words RT_STAMP_PARAM) {
-    const int n_words = group_words(sg);
-    if (n_words == 0) return;
+    if (sg.n_epairs == 0 && sg.n_fpairs == 0) return;
     const float tmin_lo = __double2float_rd(t_min), tmin_hi = __double2float_ru(t_min);
     const float ia = __builtin_amdgcn_rcpf(a);
-    const FilterRay fr = filter_ray(sg, o, d, a, ia, t_min >= 0.0);
-    const f2 OX = {o.x, o.x}, OY = {o.y, o.y}, OZ = {o.z, o.z}, AA = {a, a};
-    for (int w0 = 0; w0 < n_words; w0 += kMaskWords) {
-        const int nw = n_words - w0 < kMaskWords ? n_words - w0 : kMaskWords;
-        const uint32_t summary = filter_words(sg, fr, w0, nw, words);
+    const f2 O01 = {o.x, o.y}, O2A = {o.z, a}, D01 = {d.x, d.y}, D2 = {d.z, d.z};
+    auto visit = [&](int pair) {
+        RT_COUNT_LANES(1);
+        const float4 A = sg.fq[2 * pair], B = sg.fq[2 * pair + 1];
+        const f2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, r2 = {B.z, B.w};
+        const f2 x = pk_sub_c<0>(O01, cx), y = pk_sub_c<1>(O01, cy), z = pk_sub_c<0>(O2A, cz);
+        const f2 b = pk_mul_c<0>(D01, x) + pk_mul_c<1>(D01, y) + pk_mul_c<0>(D2, z);   // dotProduct(originCenter, direction), shapes.h:83
+        const f2 c = x * x + y * y + z * z - r2;          // lengthSquared() - radiusSquared, shapes.h:84
+        const f2 D = b * b - pk_mul_c<1>(O2A, c);         // shapes.h:86
+        uint32_t pend = (D.x >= 0.0f ? 1u : 0u) | (D.y >= 0.0f ? 2u : 0u);   // mostly 0 or one bit
+        while (pend != 0u) {
+            const bool second = (pend & 1u) == 0u;
+            pend &= pend - 1u;
+            sphere_candidate(a, ia, second ? b.y : b.x, second ? D.y : D.x, sph_prim[2 * pair + (second ? 1 : 0)], t_min, t_max, tmin_lo,
+                             tmin_hi, h RT_STAMP_ARG);
+        }
+    };
+    for (int p = 0; p < sg.n_epairs; ++p) visit(p);       // exact group first: its hit bounds t for the boxes
+    RT_STAMP(3);
+    if (sg.n_fpairs == 0) {
+        if (h.dD >= 0.0f) { resolve_exact(a, t_min, t_max, h, false, 0.0f, 0.0f, -1); }
+        return;
+    }
+    const FilterRay fr = filter_ray(sg, o, d, a, ia, t_min);
+    const int n_fwords = sg.n_fpairs >> 5;
+    for (int fw0 = 0; fw0 < n_fwords; fw0 += kMaskWords) {
+        const int nw = n_fwords - fw0 < kMaskWords ? n_fwords - fw0 : kMaskWords;
+        const uint32_t summary = filter_words(sg, fr, h.bhi, fw0, nw, words RT_STAMP_ARG);
         RT_STAMP(2);
-        walk_flagged(summary, w0, words, [&](int pair) {
-            RT_COUNT_LANES(1);
-            const float4 A = sg.fq[2 * pair], B = sg.fq[2 * pair + 1];
-            const f2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, r2 = {B.z, B.w};
-            const f2 x = OX - cx, y = OY - cy, z = OZ - cz;
-            const f2 b = x * fr.DX + y * fr.DY + z * fr.DZ;   // dotProduct(originCenter, direction), shapes.h:83
-            const f2 c = x * x + y * y + z * z - r2;          // lengthSquared() - radiusSquared, shapes.h:84
-            const f2 D = b * b - AA * c;                      // shapes.h:86
-            uint32_t pend = (D.x >= 0.0f ? 1u : 0u) | (D.y >= 0.0f ? 2u : 0u);   // mostly 0 or one bit
-            while (pend != 0u) {
-                const bool second = (pend & 1u) == 0u;
-                pend &= pend - 1u;
-                sphere_candidate(a, ia, second ? b.y : b.x, second ? D.y : D.x, sph_prim[2 * pair + (second ? 1 : 0)], t_min, t_max, tmin_lo,
-                                 tmin_hi, h RT_STAMP_ARG);
-            }
-        } RT_STAMP_ARG);
+        walk_flagged(summary, sg.n_ewords + fw0, words, visit RT_STAMP_ARG);
         RT_STAMP(3);
     }
     if (h.dD >= 0.0f) { resolve_exact(a, t_min, t_max, h, false, 0.0f, 0.0f, -1); }

@@ -29,11 +29,14 @@ ctx.lib.rt_debug_stamps(out)
 t = list(out)
 n_rays = int(rays.to_numpy("uint64", (1,))[0])
 names = ["assign+new sample", "exact group", "filter", "candidate walk", "rect+tri(+fallback)", "shade", "unwind+store", "other"]
+batches = t[1]
+t[1] = 0
 tot = sum(t[:8])
 print(f"{wl['desc']} at {spp} spp: {ms:.2f} ms, {n_rays / ms / 1e3:.0f} Mrays/s (stamped build; read shares, not speed)")
 scans = t[11]
 for n, v in zip(names, t[:8]):
     print(f"  {n:22s} {100.0 * v / tot:6.2f} %   {v / max(scans, 1):9.0f} cycles per wave-scan")
+print(f"  batches filtered per wave-scan {batches / max(scans, 1):.2f}")
 print(f"  wave-scans {scans}, rays per wave-scan {n_rays / max(scans, 1):.1f} (64 = all lanes busy)")
 print(f"  walk passes per wave-scan {t[8] / max(scans, 1):.2f}; per ray: flagged sphere pairs {t[9] / max(n_rays, 1):.2f}, sphere candidates (d >= 0) {t[10] / max(n_rays, 1):.2f}")
 ctx.close()
