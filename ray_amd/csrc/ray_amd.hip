@@ -800,7 +800,7 @@ void free_scene() {
 struct GroupBuild {
     FilterGroup fg{};
     std::vector<int> slot_item;
-    std::vector<float> fx, fy, fz, fk, bnd;
+    std::vector<float> fx, fy, fz, fk, bnd, wbnd;
 };
 void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k, float margin_k, bool finite, GroupBuild& out) {
     const int n = int(bound.size());
@@ -883,6 +883,17 @@ void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k
             mn[k] = std::min(mn[k], rel[4 * i + k] - rr); mx[k] = std::max(mx[k], rel[4 * i + k] + rr);
         }
         for (int k = 0; k < 3; ++k) { w[4 * k + h] = down(mn[k]); w[12 + 4 * k + h] = up(mx[k]); }
+    }
+    out.wbnd.assign(size_t((n_fwords + 1) / 2) * 12, 0.0f);
+    for (int fw = 0; fw < n_fwords; ++fw) {
+        const float* w = &out.bnd[size_t(fw) * 24];
+        float* q = &out.wbnd[size_t(fw / 2) * 12];
+        const int real = std::min(4, fg.n_fbatches - 4 * fw);
+        for (int k = 0; k < 3; ++k) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (int h = 0; h < real; ++h) { lo = std::min(lo, w[4 * k + h]); hi = std::max(hi, w[12 + 4 * k + h]); }
+            q[2 * k + fw % 2] = lo; q[6 + 2 * k + fw % 2] = hi;
+        }
     }
     fg.gx = float(gc[0]); fg.gy = float(gc[1]); fg.gz = float(gc[2]);
     fg.cmax = float(cmax * 1.000001) + 1.0e-30f; fg.r2max = float(r2max * 1.000001);
@@ -1132,9 +1143,9 @@ int rt_upload_scene(const RtScene* s) {
     if (upload(mk, &ds.mat_kind) || upload(mrgb, &ds.mat_rgb) || upload(mf, &ds.mat_fuzz) || upload(mir, &ds.mat_ir) ||
         upload(minv, &ds.mat_inv_ir)) return 1;
     if (upload(sgb.fx, &sgb.fg.fx) || upload(sgb.fy, &sgb.fg.fy) || upload(sgb.fz, &sgb.fg.fz) || upload(sgb.fk, &sgb.fg.fk) ||
-        upload(sgb.bnd, &sgb.fg.bnd) || upload(fq, &sgb.fg.fq)) return 1;
+        upload(sgb.bnd, &sgb.fg.bnd) || upload(sgb.wbnd, &sgb.fg.wbnd) || upload(fq, &sgb.fg.fq)) return 1;
     if (upload(tgb.fx, &tgb.fg.fx) || upload(tgb.fy, &tgb.fg.fy) || upload(tgb.fz, &tgb.fg.fz) || upload(tgb.fk, &tgb.fg.fk) ||
-        upload(tgb.bnd, &tgb.fg.bnd)) return 1;
+        upload(tgb.bnd, &tgb.fg.bnd) || upload(tgb.wbnd, &tgb.fg.wbnd)) return 1;
     tgb.fg.fq = nullptr;
     ds.sg = sgb.fg; ds.tg = tgb.fg; ds.fast_ok = finite ? 1 : 0;
     ds.light_kind = s->light_kind;

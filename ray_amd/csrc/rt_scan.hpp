@@ -53,6 +53,7 @@ struct FilterGroup {
     const float4* __restrict__ fq;   // spheres only: [2 * all pairs] per pair (cx0,cx1,cy0,cy1), (cz0,cz1,r2_0,r2_1); pads NaN
     const float* __restrict__ bnd;   // [24 per filter word] boxes of the word's 4 batches, relative to g, item radii included:
                                      // lo x0..x3, lo y0..y3, lo z0..z3, hi x0..x3, hi y0..y3, hi z0..z3
+    const float* __restrict__ wbnd;  // [12 per pair of filter words] box around each word's batches: lo x (word 0, word 1), lo y, lo z, hi x, hi y, hi z
     int n_fbatches;                  // batches that hold items (the rest of the last word is padding)
     float gx, gy, gz;                // reference point of the filter group
     float cmax, r2max;               // max |centre - g| (rounded up), max r^2 over the filter group
@@ -245,34 +246,46 @@ __device__ __forceinline__ FilterRay filter_ray(const FilterGroup& fg, V3 o, V3 
     return fr;
 }
 
+// Slab test of the ray's [t_lo, t_hi] against two widened boxes at once: n0 / n1 = this lane needs box 0 / 1
+__device__ __forceinline__ void box_pair(const FilterRay& fr, float t_hi, f2 LX, f2 LY, f2 LZ, f2 HX, f2 HY, f2 HZ, bool& n0, bool& n1) {
+    const f2 x1 = pk_fma_cc<0, 0>(fr.I01, LX, fr.CX), x2 = pk_fma_cc<0, 1>(fr.I01, HX, fr.CX);
+    const f2 y1 = pk_fma_cc<1, 0>(fr.I01, LY, fr.CY), y2 = pk_fma_cc<1, 1>(fr.I01, HY, fr.CY);
+    const f2 z1 = pk_fma_cc<0, 0>(fr.I2, LZ, fr.CZ), z2 = pk_fma_cc<0, 1>(fr.I2, HZ, fr.CZ);
+    {
+        const float tn = vmax3(vmin(x1.x, x2.x), vmin(y1.x, y2.x), vmin(z1.x, z2.x));
+        const float tf = vmin3(vmax(x1.x, x2.x), vmax(y1.x, y2.x), vmax(z1.x, z2.x));
+        n0 = vmax(tn, fr.t_lo) <= vmin(tf, t_hi);
+    }
+    {
+        const float tn = vmax3(vmin(x1.y, x2.y), vmin(y1.y, y2.y), vmin(z1.y, z2.y));
+        const float tf = vmin3(vmax(x1.y, x2.y), vmax(y1.y, y2.y), vmax(z1.y, z2.y));
+        n1 = vmax(tn, fr.t_lo) <= vmin(tf, t_hi);
+    }
+}
+
 // Level 0 + 1 for filter words [fw0, fw0 + nw) of a group: one flag bit per pair (pair p of a word <-> bit
 // 31 - p), words to this thread's LDS column; returns the mask of non-empty words. t_hi: upper bound of the
 // best t so far (boxes wholly beyond it are not needed).
 __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const FilterRay& fr, float t_hi, int fw0, int nw, uint32_t* words RT_STAMP_PARAM) {
     cf2p fx = RT_CONST_F2(fg.fx), fy = RT_CONST_F2(fg.fy), fz = RT_CONST_F2(fg.fz), fk = RT_CONST_F2(fg.fk);
     uint32_t summary = 0;
+    // level 0, words: the box around each word's 4 batches, two words per packed operation (fw0 is even)
+    uint32_t wact = 0;                                     // wave-uniform: words that some lane needs
+    for (int q = 0; 2 * q < nw; ++q) {
+        cf2p wb = RT_CONST_F2(fg.wbnd) + (fw0 / 2 + q) * 6;
+        bool n0, n1;
+        box_pair(fr, t_hi, wb[0], wb[1], wb[2], wb[3], wb[4], wb[5], n0, n1);
+        wact |= (__ballot(n0) != 0ull ? 1u : 0u) << (2 * q);
+        wact |= (__ballot(n1) != 0ull && 2 * q + 1 < nw ? 1u : 0u) << (2 * q + 1);
+    }
     for (int wi = 0; wi < nw; ++wi) {
         const int fw = fw0 + wi;
-        // level 0: the word's 4 batch boxes, two per packed operation
+        // level 0, batches: the word's 4 batch boxes
         cf2p bn = RT_CONST_F2(fg.bnd) + fw * 12;
+        if ((wact >> wi & 1u) == 0u) continue;           // no lane needs anything of this word (its summary bit stays 0)
         bool nd[4];                                        // this lane needs batch b
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f2 LX = bn[h], LY = bn[2 + h], LZ = bn[4 + h], HX = bn[6 + h], HY = bn[8 + h], HZ = bn[10 + h];
-            const f2 x1 = pk_fma_cc<0, 0>(fr.I01, LX, fr.CX), x2 = pk_fma_cc<0, 1>(fr.I01, HX, fr.CX);
-            const f2 y1 = pk_fma_cc<1, 0>(fr.I01, LY, fr.CY), y2 = pk_fma_cc<1, 1>(fr.I01, HY, fr.CY);
-            const f2 z1 = pk_fma_cc<0, 0>(fr.I2, LZ, fr.CZ), z2 = pk_fma_cc<0, 1>(fr.I2, HZ, fr.CZ);
-            {
-                const float tn = vmax3(vmin(x1.x, x2.x), vmin(y1.x, y2.x), vmin(z1.x, z2.x));
-                const float tf = vmin3(vmax(x1.x, x2.x), vmax(y1.x, y2.x), vmax(z1.x, z2.x));
-                nd[2 * h] = vmax(tn, fr.t_lo) <= vmin(tf, t_hi);
-            }
-            {
-                const float tn = vmax3(vmin(x1.y, x2.y), vmin(y1.y, y2.y), vmin(z1.y, z2.y));
-                const float tf = vmin3(vmax(x1.y, x2.y), vmax(y1.y, y2.y), vmax(z1.y, z2.y));
-                nd[2 * h + 1] = vmax(tn, fr.t_lo) <= vmin(tf, t_hi);
-            }
-        }
+        box_pair(fr, t_hi, bn[0], bn[2], bn[4], bn[6], bn[8], bn[10], nd[0], nd[1]);
+        box_pair(fr, t_hi, bn[1], bn[3], bn[5], bn[7], bn[9], bn[11], nd[2], nd[3]);
         const int real = fg.n_fbatches - fw * 4;               // padding batches hold no items
         uint32_t act = 0;                                      // wave-uniform: batches that some lane needs
 #pragma unroll
