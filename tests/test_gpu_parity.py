@@ -374,3 +374,68 @@ def test_grazing_and_far_rays_match_oracle(rt):
     for a, b in zip(got[2:], ref[2:]):
         assert O.same_values(a, b)
     assert 0.05 < (got[0] >= 0).mean() < 0.999
+
+
+def test_batch_boxes_edge_cases(rt):
+    """Stress of the batch / word boxes: clustered spheres in many batches, exact
+    duplicates at distant list positions (ties go to the later index, possibly in another batch),
+    rays parallel to one or two axes (direction components exactly +-0), rays that run along box
+    faces, rays starting inside a cluster, directions scaled over 30 binades, negative t_min and a finite
+    t_max. hitFromList through boxes + filter + exact level equals the oracle's list-order loop."""
+    rng = np.random.default_rng(23)
+    mats = [scenes.Material(scenes.MAT_LAMBERTIAN, (0.5, 0.5, 0.5))]
+    shapes = [scenes.Shape("sphere", (0.0, -1000.0, 0.0, 1000.0), 0)]
+    centres = []
+    for cl in range(12):                                   # 12 clusters x 40 spheres, flat and tall ones
+        base = rng.uniform(-20, 20, 3) * np.array([1.0, 0.2, 1.0]) + np.array([0.0, 4.0, 0.0])
+        ext = rng.choice([0.5, 2.0, 6.0], 3)
+        for _ in range(40):
+            c = np.float32(base + rng.uniform(-1, 1, 3) * ext)
+            centres.append((float(c[0]), float(c[1]), float(c[2]), float(np.float32(rng.uniform(0.05, 0.6)))))
+    grid = [(float(x), 0.25, float(z), 0.25) for x in range(-8, 8) for z in range(-8, 8)]   # touching neighbours on a lattice
+    allsph = centres + grid
+    allsph += [allsph[i] for i in rng.integers(0, len(allsph), 60)]                          # exact duplicates, later in the list
+    for s in allsph:
+        shapes.append(scenes.Shape("sphere", s, 0))
+    sc = scenes.Scene(mats, shapes, None, scenes.rayview_camera())
+    rt.upload_scene(sc, set_camera=False)
+    n = 40000
+    sph = np.array(allsph, np.float64)
+    pick = rng.integers(0, sph.shape[0], n)
+    target = sph[pick, :3] + rng.uniform(-1, 1, (n, 3)) * sph[pick, 3:4] * 1.2
+    rd = rng.standard_normal((n, 3))
+    # axis-parallel rays: zero one or two components (with both signs of zero)
+    z1 = rng.integers(0, 3, n); z2 = rng.integers(0, 3, n)
+    kind = rng.integers(0, 5, n)
+    for k in range(3):
+        rd[(kind == 1) & (z1 == k), k] = 0.0
+        rd[(kind == 2) & ((z1 == k) | (z2 == k)), k] = -0.0
+    rd[(rd == 0).all(1)] = (1.0, 0.0, 0.0)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True)
+    dist = np.exp(rng.uniform(np.log(0.01), np.log(200.0), n))[:, None]
+    ro = target - rd * dist
+    # kind 3: lattice rays running exactly along the faces of the grid spheres' boxes (y = 0 / 0.5, x = k +- 0.25)
+    m3 = kind == 3
+    ro[m3, 1] = rng.choice([0.0, 0.5, 0.25], m3.sum())
+    ro[m3, 0] = rng.integers(-8, 8, m3.sum()) + rng.choice([-0.25, 0.25, 0.0], m3.sum())
+    ro[m3, 2] = -30.0
+    rd[m3] = (0.0, 0.0, 1.0)
+    # kind 4: origin on a sphere's surface, random direction (bounce rays)
+    m4 = kind == 4
+    u = rng.standard_normal((n, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    ro[m4] = (sph[pick, :3] + sph[pick, 3:4] * u)[m4]
+    scale = np.exp2(rng.integers(-15, 16, (n, 1))).astype(np.float64)
+    ro = ro.astype(np.float32); rd = (rd * scale).astype(np.float32)
+    hits = 0
+    for t_min, t_max in [(0.001, np.inf), (-5.0, np.inf), (0.0, 3.0), (0.25, 1.0e4)]:
+        got = rt.hit_rays(ro, rd, t_min, t_max)
+        ref = O.hit_rays(sc, ro, rd, t_min, t_max)
+        assert np.array_equal(got[0], ref[0]), (t_min, t_max, np.flatnonzero(got[0] != ref[0])[:10])
+        assert O.bits_equal(got[1], ref[1])
+        for a, b in zip(got[2:], ref[2:]):
+            assert O.same_values(a, b)
+        hits += int((got[0] > 0).sum())
+    assert hits > n                                         # plenty of hits on the small spheres, not only the ground
+    # duplicates: some winning index must be one of the appended copies (ties go to the later entry)
+    first_dup = 1 + len(centres) + len(grid)
+    assert (rt.hit_rays(ro, rd, 0.001, np.inf)[0] > first_dup).any()
