@@ -217,24 +217,24 @@ __device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const R
 __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r, double t_min, Hit& h, uint32_t* words RT_STAMP_PARAM) {
     const FilterGroup& tg = sc.tg;
     if (tg.n_epairs == 0 && tg.n_fpairs == 0) return;
-    auto visit = [&](int pair) {
+    auto visit = [&](int item) {       // an item: up to two triangles under one bounding sphere
 #pragma unroll 1
-        for (int hh = 0; hh < 4; ++hh) {   // two items of up to two triangles each
-            const int slot = 4 * pair + hh;
+        for (int hh = 0; hh < 2; ++hh) {
+            const int slot = 2 * item + hh;
             const int idx = sc.tri_prim[slot];
             double t;
             if (idx >= 0 && tri_t(r, sc.tri + 16 * slot, t_min, h.t, idx, h.prim, &t)) { h.t = t; h.prim = idx; }
         }
     };
-    for (int p = 0; p < tg.n_epairs; ++p) visit(p);
+    for (int p = 0; p < 2 * tg.n_epairs; ++p) visit(p);
     if (tg.n_fpairs == 0) return;
     const FilterRay fr = filter_ray(tg, r.o, r.d, r.dl2, __builtin_amdgcn_rcpf(r.dl2), t_min);
     const int n_fwords = tg.n_fpairs >> 5;
-    for (int fw0 = 0; fw0 < n_fwords; fw0 += kMaskWords) {
-        const int nw = n_fwords - fw0 < kMaskWords ? n_fwords - fw0 : kMaskWords;
-        const uint32_t summary = filter_words(tg, fr, __double2float_ru(h.t), fw0, nw, words RT_STAMP_ARG);
+    for (int fw0 = 0; fw0 < n_fwords; fw0 += kMaskWords / 2) {
+        const int nw = n_fwords - fw0 < kMaskWords / 2 ? n_fwords - fw0 : kMaskWords / 2;
+        const uint32_t summary = filter_words<true>(tg, fr, __double2float_ru(h.t), fw0, nw, words RT_STAMP_ARG);
         RT_STAMP(2);
-        walk_flagged(summary, tg.n_ewords + fw0, words, visit RT_STAMP_ARG);
+        walk_flagged_items(summary, tg.n_ewords + fw0, words, visit RT_STAMP_ARG);
         RT_STAMP(3);
     }
 }

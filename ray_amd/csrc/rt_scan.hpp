@@ -266,6 +266,9 @@ __device__ __forceinline__ void box_pair(const FilterRay& fr, float t_hi, f2 LX,
 // Level 0 + 1 for filter words [fw0, fw0 + nw) of a group: one flag bit per pair (pair p of a word <-> bit
 // 31 - p), words to this thread's LDS column; returns the mask of non-empty words. t_hi: upper bound of the
 // best t so far (boxes wholly beyond it are not needed).
+// ITEMS: one flag per ITEM instead (for kinds whose exact test is expensive per item: triangles): item 0's
+// flags of word wi at words[wi], item 1's at words[wi + kMaskWords / 2]; nw <= kMaskWords / 2.
+template <bool ITEMS = false>
 __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const FilterRay& fr, float t_hi, int fw0, int nw, uint32_t* words RT_STAMP_PARAM) {
     cf2p fx = RT_CONST_F2(fg.fx), fy = RT_CONST_F2(fg.fy), fz = RT_CONST_F2(fg.fz), fk = RT_CONST_F2(fg.fk);
     uint32_t summary = 0;
@@ -291,12 +294,12 @@ __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const Fi
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) act |= (__ballot(nd[bb]) != 0ull && bb < real ? 1u : 0u) << bb;
         RT_BATCHES(act);
-        uint32_t m = 0xffffffffu;                              // bit set: pair NOT flagged
+        uint32_t m = 0xffffffffu, m1 = 0xffffffffu;            // bit set: pair (ITEMS: item 0, item 1) NOT flagged
         if (act != 0u) {
-            m = 0;
+            m = 0; m1 = 0;
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
-                if ((act >> bb & 1u) == 0u) { m = (m << 8) | 0xffu; continue; }
+                if ((act >> bb & 1u) == 0u) { m = (m << 8) | 0xffu; if (ITEMS) m1 = (m1 << 8) | 0xffu; continue; }
                 const int batch = fw * 4 + bb;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
@@ -310,21 +313,29 @@ __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const Fi
                     Q = pk_fma_cv<1>(fr.W01, Y, Q);
                     Q = pk_fma_cv<0>(fr.W2, Z, Q);
                     const f2 T = __builtin_elementwise_fma(bq, bq, Q);   // >= 0 (sign bit clear): flagged
-                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x) & __float_as_uint(T.y), 31);
+                    if (ITEMS) {
+                        m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x), 31);
+                        m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(T.y), 31);
+                    } else {
+                        m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x) & __float_as_uint(T.y), 31);
+                    }
                 }
                 m |= nd[bb] ? 0u : 0xffu;     // this lane does not need the batch
+                if (ITEMS) m1 |= nd[bb] ? 0u : 0xffu;
             }
         }
-        const uint32_t flagged = ~m;
-        words[wi * kScanBlock] = flagged;
+        const uint32_t flagged = ITEMS ? ~(m & m1) : ~m;
+        words[wi * kScanBlock] = ~m;
+        if (ITEMS) words[(wi + kMaskWords / 2) * kScanBlock] = ~m1;
         summary |= (flagged != 0u ? 1u : 0u) << wi;
     }
     return summary;
 }
 
 // Level 2 driver: each lane walks its own flagged pairs of the chunk and calls visit(pair).
+// w0: word index of the chunk in pair space.
 template <class Visit>
-__device__ __forceinline__ void walk_flagged(uint32_t summary, int w0, const uint32_t* words, Visit&& visit RT_STAMP_PARAM) {   // w0: word index of the chunk in pair space
+__device__ __forceinline__ void walk_flagged(uint32_t summary, int w0, const uint32_t* words, Visit&& visit RT_STAMP_PARAM) {
     uint32_t cur = 0;
     int wbase = 0;
     while (cur != 0u || summary != 0u) {
@@ -338,6 +349,28 @@ __device__ __forceinline__ void walk_flagged(uint32_t summary, int w0, const uin
         const int p = __builtin_clz(cur);
         cur &= ~(0x80000000u >> p);
         visit(wbase + p);
+    }
+}
+// The same over item flags (filter_words<true>): calls visit(2 * pair + item) for every flagged item.
+template <class Visit>
+__device__ __forceinline__ void walk_flagged_items(uint32_t summary, int w0, const uint32_t* words, Visit&& visit RT_STAMP_PARAM) {
+    uint32_t cur0 = 0, cur1 = 0;
+    int wbase = 0;
+    while ((cur0 | cur1) != 0u || summary != 0u) {
+        RT_COUNT(0);
+        if ((cur0 | cur1) == 0u) {
+            const int wi = __builtin_ctz(summary);
+            summary &= summary - 1u;
+            cur0 = words[wi * kScanBlock];
+            cur1 = words[(wi + kMaskWords / 2) * kScanBlock];
+            wbase = (w0 + wi) * 32;
+        }
+        const bool second = cur0 == 0u;                    // item 0 flags of the word first, then item 1
+        const uint32_t c = second ? cur1 : cur0;
+        const int p = __builtin_clz(c);
+        const uint32_t rest = c & ~(0x80000000u >> p);
+        if (second) cur1 = rest; else cur0 = rest;
+        visit(2 * (wbase + p) + (second ? 1 : 0));
     }
 }
 
