@@ -231,6 +231,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     const FilterRay fr = filter_ray(tg, r.o, r.d, r.dl2, __builtin_amdgcn_rcpf(r.dl2), t_min);
     const int n_fwords = tg.n_fpairs >> 5;
     for (int fw0 = 0; fw0 < n_fwords; fw0 += kMaskWords / 2) {
+        if (!chunk_needed(tg, fr, __double2float_ru(h.t), fw0 / (kMaskWords / 2))) continue;
         const int nw = n_fwords - fw0 < kMaskWords / 2 ? n_fwords - fw0 : kMaskWords / 2;
         const uint32_t summary = filter_words<true>(tg, fr, __double2float_ru(h.t), fw0, nw, words RT_STAMP_ARG);
         RT_STAMP(2);
@@ -800,9 +801,9 @@ void free_scene() {
 struct GroupBuild {
     FilterGroup fg{};
     std::vector<int> slot_item;
-    std::vector<float> fx, fy, fz, fk, bnd, wbnd;
+    std::vector<float> fx, fy, fz, fk, bnd, wbnd, cbnd;
 };
-void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k, float margin_k, bool finite, GroupBuild& out) {
+void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k, float margin_k, bool finite, int chunk_words, GroupBuild& out) {
     const int n = int(bound.size());
     std::vector<char> in_filter(n, 0);
     double gc[3] = {0, 0, 0};
@@ -883,6 +884,20 @@ void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k
             mn[k] = std::min(mn[k], rel[4 * i + k] - rr); mx[k] = std::max(mx[k], rel[4 * i + k] + rr);
         }
         for (int k = 0; k < 3; ++k) { w[4 * k + h] = down(mn[k]); w[12 + 4 * k + h] = up(mx[k]); }
+    }
+    fg.chunk_words = chunk_words;
+    const int n_chunks = (n_fwords + chunk_words - 1) / chunk_words;
+    out.cbnd.assign(size_t((n_chunks + 1) / 2) * 12, 0.0f);
+    for (int ci = 0; ci < n_chunks; ++ci) {
+        float* q = &out.cbnd[size_t(ci / 2) * 12];
+        for (int k = 0; k < 3; ++k) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (int b = ci * chunk_words * 4; b < std::min(fg.n_fbatches, (ci + 1) * chunk_words * 4); ++b) {
+                const float* w = &out.bnd[size_t(b / 4) * 24];
+                lo = std::min(lo, w[4 * k + b % 4]); hi = std::max(hi, w[12 + 4 * k + b % 4]);
+            }
+            q[2 * k + ci % 2] = lo; q[6 + 2 * k + ci % 2] = hi;
+        }
     }
     out.wbnd.assign(size_t((n_fwords + 1) / 2) * 12, 0.0f);
     for (int fw = 0; fw < n_fwords; ++fw) {
@@ -1031,7 +1046,7 @@ int rt_upload_scene(const RtScene* s) {
             bound[i] = sph[i]; r2k[i] = sph[i].w * sph[i].w;   // radiusSquared, shapes.h:73
             if (!(std::fabs(sph[i].x) <= 1.0e7f && std::fabs(sph[i].y) <= 1.0e7f && std::fabs(sph[i].z) <= 1.0e7f && std::fabs(sph[i].w) <= 1.0e7f)) finite = false;
         }
-        build_group(bound, r2k, kMarginK, finite, sgb);
+        build_group(bound, r2k, kMarginK, finite, kMaskWords, sgb);
         const float nanf_ = std::numeric_limits<float>::quiet_NaN();
         std::vector<float4> sph2(sgb.slot_item.size(), make_float4(nanf_, nanf_, nanf_, 1.0f));
         std::vector<int> prim2(sgb.slot_item.size(), -1);
@@ -1088,7 +1103,7 @@ int rt_upload_scene(const RtScene* s) {
             r2k.push_back(q[15] * 1.0001f);
             ++i;
         }
-        build_group(bound, r2k, kMarginKTri, finite, tgb);
+        build_group(bound, r2k, kMarginKTri, finite, kMaskWords / 2, tgb);
         const float nanf_ = std::numeric_limits<float>::quiet_NaN();
         std::vector<float> tri2(tgb.slot_item.size() * 2 * 16, nanf_);   // two triangle slots per item slot
         std::vector<int> prim2(tgb.slot_item.size() * 2, -1);
@@ -1143,9 +1158,9 @@ int rt_upload_scene(const RtScene* s) {
     if (upload(mk, &ds.mat_kind) || upload(mrgb, &ds.mat_rgb) || upload(mf, &ds.mat_fuzz) || upload(mir, &ds.mat_ir) ||
         upload(minv, &ds.mat_inv_ir)) return 1;
     if (upload(sgb.fx, &sgb.fg.fx) || upload(sgb.fy, &sgb.fg.fy) || upload(sgb.fz, &sgb.fg.fz) || upload(sgb.fk, &sgb.fg.fk) ||
-        upload(sgb.bnd, &sgb.fg.bnd) || upload(sgb.wbnd, &sgb.fg.wbnd) || upload(fq, &sgb.fg.fq)) return 1;
+        upload(sgb.bnd, &sgb.fg.bnd) || upload(sgb.wbnd, &sgb.fg.wbnd) || upload(sgb.cbnd, &sgb.fg.cbnd) || upload(fq, &sgb.fg.fq)) return 1;
     if (upload(tgb.fx, &tgb.fg.fx) || upload(tgb.fy, &tgb.fg.fy) || upload(tgb.fz, &tgb.fg.fz) || upload(tgb.fk, &tgb.fg.fk) ||
-        upload(tgb.bnd, &tgb.fg.bnd) || upload(tgb.wbnd, &tgb.fg.wbnd)) return 1;
+        upload(tgb.bnd, &tgb.fg.bnd) || upload(tgb.wbnd, &tgb.fg.wbnd) || upload(tgb.cbnd, &tgb.fg.cbnd)) return 1;
     tgb.fg.fq = nullptr;
     ds.sg = sgb.fg; ds.tg = tgb.fg; ds.fast_ok = finite ? 1 : 0;
     ds.light_kind = s->light_kind;

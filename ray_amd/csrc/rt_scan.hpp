@@ -54,6 +54,8 @@ struct FilterGroup {
     const float* __restrict__ bnd;   // [24 per filter word] boxes of the word's 4 batches, relative to g, item radii included:
                                      // lo x0..x3, lo y0..y3, lo z0..z3, hi x0..x3, hi y0..y3, hi z0..z3
     const float* __restrict__ wbnd;  // [12 per pair of filter words] box around each word's batches: lo x (word 0, word 1), lo y, lo z, hi x, hi y, hi z
+    const float* __restrict__ cbnd;  // [12 per pair of chunks] the same around each chunk of chunk_words filter words
+    int chunk_words;                 // filter words per chunk: kMaskWords (one flag per pair) or kMaskWords / 2 (one per item)
     int n_fbatches;                  // batches that hold items (the rest of the last word is padding)
     float gx, gy, gz;                // reference point of the filter group
     float cmax, r2max;               // max |centre - g| (rounded up), max r^2 over the filter group
@@ -261,6 +263,15 @@ __device__ __forceinline__ void box_pair(const FilterRay& fr, float t_hi, f2 LX,
         const float tf = vmin3(vmax(x1.y, x2.y), vmax(y1.y, y2.y), vmax(z1.y, z2.y));
         n1 = vmax(tn, fr.t_lo) <= vmin(tf, t_hi);
     }
+}
+
+// Level 0, chunks: does any lane of the wave need chunk ci (wave-uniform answer)? Groups of one chunk skip the test.
+__device__ __forceinline__ bool chunk_needed(const FilterGroup& fg, const FilterRay& fr, float t_hi, int ci) {
+    if ((fg.n_fpairs >> 5) <= fg.chunk_words) return true;
+    cf2p cb = RT_CONST_F2(fg.cbnd) + (ci >> 1) * 6;
+    bool n0, n1;
+    box_pair(fr, t_hi, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], n0, n1);
+    return __ballot((ci & 1) ? n1 : n0) != 0ull;
 }
 
 // Level 0 + 1 for filter words [fw0, fw0 + nw) of a group: one flag bit per pair (pair p of a word <-> bit
