@@ -318,6 +318,7 @@ __device__ __forceinline__ double light_pdf_value(const DevScene& sc, V3 o, V3 v
         V3 co = v3(s.x, s.y, s.z) - o;
         double cos_theta_max = sqrt64(double(1 - s.w * s.w / length_squared(co)));
         double solid_angle = 2 * kPi * (1 - cos_theta_max);
+        if (recip_range_ok(solid_angle)) return div64(1.0, recip64(solid_angle));
         return 1 / solid_angle;
     }
     if (sc.light_kind == RT_PRIM_XY_RECT || sc.light_kind == RT_PRIM_XZ_RECT) {

@@ -105,11 +105,13 @@ __device__ __forceinline__ void hit_state_init(HitState& h, double t_max) {
 }
 // sphere::hit's root selection (shapes.h:90-97) in FP64 against the exact best
 __device__ __forceinline__ void exact_accept(float a, float b, float D, int idx, double t_min, HitState& h) {
+    // kMinA <= a <= kMaxA and |b|, sqrt(D) finite floats (ray_in_fast_range): the shared-reciprocal division is `/` here
     double sqrtd = sqrt64(double(D));
     double nb = double(-b);
-    double root = (nb - sqrtd) / double(a);
+    const Recip64 ra = recip64(double(a));
+    double root = div64(nb - sqrtd, ra);
     if (reject_t(root, t_min, h.bt, idx, h.idx)) {
-        root = (nb + sqrtd) / double(a);
+        root = div64(nb + sqrtd, ra);
         if (reject_t(root, t_min, h.bt, idx, h.idx)) return;
     }
     h.bt = root; h.idx = idx;
