@@ -218,6 +218,8 @@ def main():
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 4), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
                          "kernel": "render_kernel", "kernel_ms": round(k_ms, 3), "flops_per_ray": fpr,
+                         "accounting": "algorithmic (SURVEY 8d): closest-hit scans x primitives x flops of the reference's test; "
+                                       "the box hierarchy and the packed filter answer most tests without evaluating them",
                          "accumulator_GBps": round(W * H * 16 * (2 if False else 1) / (k_ms * 1e-3) / 1e9, 3) if k_ms > 0 else None},
         }
         if not args.no_cpu and world == 1:
