@@ -1,7 +1,13 @@
 // Closest-hit scan over the sphere arrays for gfx950 (hitFromList, hitPosition.cpp:6-22, over
-// sphere::hit, shapes.h:77-97), brute force: every ray is tested against every sphere.
-//
-// Two levels, results bit-identical to the reference's arithmetic:
+// sphere::hit, shapes.h:77-97). The contract is the brute-force loop's: every sphere is a candidate for
+// every ray and the result is bit-identical to the reference's arithmetic. Three levels decide, with
+// growing cost, which spheres a ray still has to be tested against exactly:
+//  0. BOXES: the filter group is stored in spatially compact batches of 8 pairs (16 items), each with an
+//     axis-aligned box around its items; words of 4 batches and chunks of words have boxes too. A slab
+//     test of the ray against a box, widened by the ray's filter margin, tells per lane whether the ray
+//     can come near any item inside [max(t_min, 0), best t so far]. A batch (word, chunk) that no lane
+//     of the wave needs is not filtered at all (wave-uniform branch); a lane that does not need a batch
+//     gets no flags from it. No item that the reference could hit is ever dropped.
 //  1. FILTER: a conservative line-sphere test in packed FMA arithmetic (v_pk_fma_f32, two spheres per
 //     instruction, 8 instructions per pair; sphere data wave-uniform through scalar loads). It flags
 //     every pair that holds a sphere whose REFERENCE discriminant d = b*b - a*c (separately rounded
@@ -13,14 +19,8 @@
 //     candidate so far; the reference's FP64 sqrt / divide / interval tests (shapes.h:90-97) run only
 //     for the candidate that survives, or when two candidates' bounds overlap (ties included).
 // Spheres that are huge or far from the rest (the ground sphere) would blow up the filter margin of
-// every ray; rt_upload_scene puts them in the "exact group", whose pairs are always flagged.
-//  0. BATCH BOXES: the filter group is stored in spatially compact batches of 8 pairs (16 items), each
-//     with an axis-aligned box around its items. A slab test of the ray against the box, widened by the
-//     ray's filter margin, tells per lane whether the ray can come near any item of the batch inside
-//     [max(t_min, 0), best t so far]. A batch that no lane of the wave needs is not filtered at all
-//     (wave-uniform branch); a lane that does not need it gets no flags from it. The exact group is
-//     visited first, so the ground's hit already bounds t when the boxes are tested.
-//     Still brute force in the contract's sense: no item that the reference could hit is ever dropped.
+// every ray; rt_upload_scene puts them in the "exact group", whose pairs are always visited, and first,
+// so that the ground's hit already bounds t when the boxes are tested.
 #pragma once
 #include "rt_device.hpp"
 
