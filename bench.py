@@ -154,7 +154,7 @@ def main():
     rays = torch.zeros(1, dtype=torch.int64, device=dev)
 
     # work split (ray_amd/dist.py): spp-split = every rank renders all pixels and a slice of the samples;
-    # tile-split = every rank renders all samples of a band of rows; both end in one all-reduce
+    # tile-split = every rank renders all samples of its interleaved 8-row bands; both end in one all-reduce
     pl = rdist.plan(wl["split"], W, H, spp, rank, world)
     s0, s1 = pl["spp_begin"], pl["spp_begin"] + pl["spp_count"]
     y0, yc = pl["y_begin"], pl["y_count"]
@@ -163,7 +163,8 @@ def main():
     def step():
         if pl["zero_first"]:
             accum.zero_()
-        ctx.render_into(W, H, accum, s1 - s0, depth, seed=seed, flags=0, y_begin=y0, y_count=yc, spp_begin=s0, rays=rays)
+        ctx.render_into(W, H, accum, s1 - s0, depth, seed=seed, flags=0, y_begin=y0, y_count=yc, spp_begin=s0, rays=rays,
+                        band_first=pl["band_first"], band_stride=pl["band_stride"])
         ms, _ = ctx.last_kernel_ms()
         rdist.reduce_accumulators(accum, world)
         return ms

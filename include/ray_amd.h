@@ -139,6 +139,14 @@ int rt_hit_rays(int64_t n, const float* d_origin, const float* d_dir, double t_m
 int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth,
               uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
 
+/* rt_render for an interleaved share of the image: the frame is cut into bands of 8 rows (band b =
+ * rows [8b, 8b + 8)), and the call renders bands band_first, band_first + band_stride, ... Other rows
+ * are not touched. With band_first = rank and band_stride = number of GPUs every GPU gets the same mix
+ * of sky and geometry rows (the balanced form of the image-tile split; the reference renders random
+ * pixels on one thread, rayview.cpp:72-76, so it has no counterpart). Same arguments otherwise.     */
+int rt_render_bands(int w, int h, int band_first, int band_stride, int spp_begin, int spp_count, int depth,
+                    uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
+
 /* Number of closest-hit scans of the last RT_RENDER_VERIFY render whose fast result (primitive or t
  * bits) differed from hitFromList's list-order loop (hitPosition.cpp:6-22) run on the same ray. No
  * counterpart in the reference: it checks the sphere filter of rt_scan.hpp at full frame sizes.     */

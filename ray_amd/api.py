@@ -144,17 +144,23 @@ class Context:
             b.free()
         return out
 
-    def render_into(self, W, H, accum, spp, depth, seed=0, flags=0, y_begin=0, y_count=None, spp_begin=0, rays=None):
+    def render_into(self, W, H, accum, spp, depth, seed=0, flags=0, y_begin=0, y_count=None, spp_begin=0, rays=None,
+                    band_first=0, band_stride=1):
         """rt_render into a caller-owned device accumulator ([H][W][4] float32: DeviceBuffer, torch
-        tensor or raw pointer). `rays`: optional device uint64 counter."""
+        tensor or raw pointer). `rays`: optional device uint64 counter. band_stride > 1: rt_render_bands
+        (8-row bands band_first, band_first + band_stride, ... of the whole frame)."""
+        if band_stride != 1 or band_first != 0:
+            self._check(self.lib.rt_render_bands(W, H, band_first, band_stride, spp_begin, spp, depth, seed, flags,
+                                                 _dev_ptr(accum), _dev_ptr(rays)))
+            return
         self._check(self.lib.rt_render(W, H, y_begin, H if y_count is None else y_count, spp_begin, spp, depth, seed, flags,
                                        _dev_ptr(accum), _dev_ptr(rays)))
 
-    def render(self, W, H, spp, depth, seed=0, flags=0, y_begin=0, y_count=None, spp_begin=0):
+    def render(self, W, H, spp, depth, seed=0, flags=0, y_begin=0, y_count=None, spp_begin=0, band_first=0, band_stride=1):
         """Convenience: render into a fresh zeroed accumulator and return (accum[H,W,4], n_rays)."""
         acc = self.alloc(W * H * 16).zero()
         rays = self.alloc(8).zero()
-        self.render_into(W, H, acc, spp, depth, seed, flags, y_begin, y_count, spp_begin, rays)
+        self.render_into(W, H, acc, spp, depth, seed, flags, y_begin, y_count, spp_begin, rays, band_first, band_stride)
         out = acc.to_numpy(np.float32, (H, W, 4))
         n = int(rays.to_numpy(np.uint64, (1,))[0])
         acc.free(); rays.free()

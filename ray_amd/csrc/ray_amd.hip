@@ -517,6 +517,7 @@ constexpr int kTile = 8;             // work unit handed to a wave: one 8x8 pixe
 
 struct RenderArgs {
     int W, H, y_begin, y_count, spp_begin, spp_count, depth;
+    int band_first, band_stride, tiles_y;          // tile row k covers rows y_begin + (band_first + k * band_stride) * 8 + [0, 8)
     uint64_t seed;
     uint32_t flags;
     float4* __restrict__ accum;
@@ -538,8 +539,8 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
     __shared__ uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int tiles_x = (ra.W + kTile - 1) / kTile, tiles_y = (ra.y_count + kTile - 1) / kTile;
-    const int total = tiles_x * tiles_y * 64;
+    const int tiles_x = (ra.W + kTile - 1) / kTile;
+    const int total = tiles_x * ra.tiles_y * 64;
     __shared__ float4 s_stack[kLdsLevels * kBlock];
     PathStack st; st.lds = s_stack + threadIdx.x; st.base = ra.stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
     const bool normals = (ra.flags & RT_RENDER_NORMALS) != 0;
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
                 const int idx = q_cur + rank;
                 const int tile = idx >> 6, in = idx & 63;
                 x = (tile % tiles_x) * kTile + (in & 7);
-                y = ra.y_begin + (tile / tiles_x) * kTile + (in >> 3);
+                y = ra.y_begin + (ra.band_first + (tile / tiles_x) * ra.band_stride) * kTile + (in >> 3);
                 if (x < ra.W && y < ra.y_begin + ra.y_count) {
                     have = true; path = false;
                     pix = uint32_t(y) * uint32_t(ra.W) + uint32_t(x);
@@ -645,10 +646,14 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
 }
 
 // depth <= 0 or no samples: every sample is black and no ray is traced (calc.cpp:96-97)
-__global__ void render_black_kernel(int W, int y_begin, int y_count, int spp_count, uint32_t flags, float4* __restrict__ accum) {
+__global__ void render_black_kernel(int W, int y_begin, int y_count, int band_first, int band_stride, int tiles_y, int spp_count, uint32_t flags,
+                                    float4* __restrict__ accum) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= W * y_count) return;
-    size_t pix = size_t(y_begin) * W + i;
+    if (i >= W * tiles_y * kTile) return;
+    const int r = i / W, x = i - r * W;
+    const int y = y_begin + (band_first + (r / kTile) * band_stride) * kTile + r % kTile;
+    if (y >= y_begin + y_count) return;
+    size_t pix = size_t(y) * W + x;
     float4 a = make_float4(0.0f, 0.0f, 0.0f, float(spp_count));
     if (flags & RT_RENDER_ACCUMULATE) {
         float4 o = accum[pix];
@@ -1271,23 +1276,20 @@ int rt_trace_rays(int64_t n, const float* d_origin, const float* d_dir, int dept
     return finish_timed(1);
 }
 
-int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth, uint64_t seed, uint32_t flags,
-              float* d_accum, uint64_t* d_rays) {
-    if (need_scene_cam()) return 1;
-    if (w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL) return fail("rt_render: bad size %dx%d", w, h);
-    if (y_begin < 0 || y_count < 0 || y_begin + y_count > h) return fail("rt_render: rows [%d,+%d) outside 0..%d", y_begin, y_count, h);
-    if (spp_begin < 0 || spp_count < 0) return fail("rt_render: bad sample range [%d,+%d)", spp_begin, spp_count);
-    if (depth < 0 || depth > 128) return fail("rt_render: depth %d outside 0..128", depth);
-    if (!d_accum) return fail("rt_render: null accumulator");
-    if (y_count == 0) { g.last_ms = 0; g.last_launches = 0; return 0; }
+static int render_impl(const char* who, int w, int h, int y_begin, int y_count, int band_first, int band_stride, int tiles_y, int spp_begin,
+                       int spp_count, int depth, uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays) {
+    if (spp_begin < 0 || spp_count < 0) return fail("%s: bad sample range [%d,+%d)", who, spp_begin, spp_count);
+    if (depth < 0 || depth > 128) return fail("%s: depth %d outside 0..128", who, depth);
+    if (!d_accum) return fail("%s: null accumulator", who);
+    if (tiles_y == 0) { g.last_ms = 0; g.last_launches = 0; return 0; }
     if (spp_count == 0 || depth == 0) {   // no ray is traced: every sample is black (calc.cpp:96-97)
-        int n = w * y_count;
+        int n = w * tiles_y * kTile;
         HIP_OK(hipEventRecord(g.ev0, g.stream));
-        hipLaunchKernelGGL(render_black_kernel, dim3((n + 255) / 256), dim3(256), 0, g.stream, w, y_begin, y_count, spp_count, flags,
-                           reinterpret_cast<float4*>(d_accum));
+        hipLaunchKernelGGL(render_black_kernel, dim3((n + 255) / 256), dim3(256), 0, g.stream, w, y_begin, y_count, band_first, band_stride, tiles_y,
+                           spp_count, flags, reinterpret_cast<float4*>(d_accum));
         return finish_timed(1);
     }
-    const int n_tiles = ((w + kTile - 1) / kTile) * ((y_count + kTile - 1) / kTile);   // one 8x8 tile per wave at a time
+    const int n_tiles = ((w + kTile - 1) / kTile) * tiles_y;   // one 8x8 tile per wave at a time
     int resident = g.prop.multiProcessorCount * g.render_blocks_per_cu;
 #ifdef RT_STAMPS
     if (const char* e = getenv("RT_BPC")) resident = g.prop.multiProcessorCount * atoi(e);   // diagnostic: blocks per CU
@@ -1297,6 +1299,7 @@ int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_cou
     if (ensure_stack(depth, grid)) return 1;
     RenderArgs ra{};
     ra.W = w; ra.H = h; ra.y_begin = y_begin; ra.y_count = y_count; ra.spp_begin = spp_begin; ra.spp_count = spp_count; ra.depth = depth;
+    ra.band_first = band_first; ra.band_stride = band_stride; ra.tiles_y = tiles_y;
     ra.seed = seed; ra.flags = flags;
     ra.accum = reinterpret_cast<float4*>(d_accum); ra.stack = static_cast<float4*>(g.stack);
     ra.rays_out = reinterpret_cast<unsigned long long*>(d_rays);
@@ -1314,6 +1317,25 @@ int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_cou
     if (verify) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
     else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
     return finish_timed(1);
+}
+
+int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth, uint64_t seed, uint32_t flags,
+              float* d_accum, uint64_t* d_rays) {
+    if (need_scene_cam()) return 1;
+    if (w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL) return fail("rt_render: bad size %dx%d", w, h);
+    if (y_begin < 0 || y_count < 0 || y_begin + y_count > h) return fail("rt_render: rows [%d,+%d) outside 0..%d", y_begin, y_count, h);
+    return render_impl("rt_render", w, h, y_begin, y_count, 0, 1, (y_count + kTile - 1) / kTile, spp_begin, spp_count, depth, seed, flags, d_accum,
+                       d_rays);
+}
+
+int rt_render_bands(int w, int h, int band_first, int band_stride, int spp_begin, int spp_count, int depth, uint64_t seed, uint32_t flags,
+                    float* d_accum, uint64_t* d_rays) {
+    if (need_scene_cam()) return 1;
+    if (w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL) return fail("rt_render_bands: bad size %dx%d", w, h);
+    if (band_first < 0 || band_stride <= 0) return fail("rt_render_bands: bad bands first=%d stride=%d", band_first, band_stride);
+    const int n_bands = (h + kTile - 1) / kTile;
+    const int mine = band_first >= n_bands ? 0 : (n_bands - band_first + band_stride - 1) / band_stride;
+    return render_impl("rt_render_bands", w, h, 0, h, band_first, band_stride, mine, spp_begin, spp_count, depth, seed, flags, d_accum, d_rays);
 }
 
 #ifdef RT_STAMPS

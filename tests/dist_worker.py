@@ -21,12 +21,16 @@ def main():
     W, H, spp, depth, seed = 48, 27, 6, 6, 0xC0FFEE
     sc = scenes.get_scene("random", half=2)
     ok = True
-    for split in ("spp", "tile"):
+    for split in ("spp", "tile", "rows"):
         p = rdist.plan(split, W, H, spp, rank, world)
         acc = torch.zeros((H, W, 4), dtype=torch.float32)
-        part, rays = O.render(sc, W, H, p["spp_count"], depth, rng_mode=1, seed64=seed, math_mode=1,
-                              y_begin=p["y_begin"], y_count=p["y_count"], spp_begin=p["spp_begin"])
-        acc += torch.from_numpy(part)
+        rays = 0
+        bands = rdist.band_rows(H, p["band_first"], p["band_stride"]) if p["band_stride"] > 1 else [(p["y_begin"], p["y_count"])]
+        for y0, yc in bands:                              # the oracle renders one contiguous band per call
+            part, n = O.render(sc, W, H, p["spp_count"], depth, rng_mode=1, seed64=seed, math_mode=1,
+                               y_begin=y0, y_count=yc, spp_begin=p["spp_begin"])
+            acc += torch.from_numpy(part)
+            rays += n
         rdist.reduce_accumulators(acc, world)
         r = torch.tensor([rays], dtype=torch.int64)
         dist.all_reduce(r)
@@ -35,7 +39,7 @@ def main():
             got = acc.numpy()
             assert int(r.item()) == rays_full, (int(r.item()), rays_full)
             assert (got[..., 3] == spp).all()
-            if split == "tile":
+            if split != "spp":
                 ok &= np.array_equal(got, full, equal_nan=True)          # disjoint bands + zeros: bit-exact
             else:
                 ok &= np.allclose(got[..., :3], full[..., :3], rtol=2e-6, atol=1e-6)   # (a+b)+(c+d) vs sequential

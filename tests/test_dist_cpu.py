@@ -23,11 +23,17 @@ def test_splits_tile_the_range():
     assert rdist.spp_split(256, 3, 8) == (96, 32)
     with pytest.raises(ValueError):
         rdist.spp_split(8, 2, 2)
+    p = rdist.plan("rows", 64, 36, 16, 1, 4)
+    assert p == dict(y_begin=9, y_count=9, band_first=0, band_stride=1, spp_begin=0, spp_count=16, zero_first=True)
     p = rdist.plan("tile", 64, 36, 16, 1, 4)
-    assert p == dict(y_begin=9, y_count=9, spp_begin=0, spp_count=16, zero_first=True)
+    assert p == dict(y_begin=0, y_count=36, band_first=1, band_stride=4, spp_begin=0, spp_count=16, zero_first=True)
     assert rdist.plan("tile", 64, 36, 16, 0, 1)["zero_first"] is False
     with pytest.raises(ValueError):
-        rdist.plan("rows", 1, 1, 1, 0, 1)
+        rdist.plan("columns", 1, 1, 1, 0, 1)
+    for H in (1, 8, 27, 36, 2160):                      # the ranks' bands tile [0, H) exactly once
+        for world in (1, 2, 3, 8):
+            rows = sorted(r for k in range(world) for r in rdist.band_rows(H, k, world))
+            assert rows[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(rows, rows[1:])) and rows[-1][0] + rows[-1][1] == H
 
 
 @pytest.mark.parametrize("world", [2, 3])

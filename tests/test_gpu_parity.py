@@ -202,6 +202,23 @@ def test_sample_and_row_splits_compose(rt):
     rt.render_into(W, H, acc, 6, 8, seed=9, y_begin=0, y_count=23)
     rt.render_into(W, H, acc, 6, 8, seed=9, y_begin=23, y_count=17)
     assert O.same_values(acc.to_numpy(np.float32, (H, W, 4)), full)
+    # interleaved 8-row bands (rt_render_bands): the shares of 3 "ranks" are disjoint and tile the frame;
+    # a ragged height (last band of 3 rows), more ranks than bands, and the black (depth 0) path
+    for Hb, world in [(H, 3), (43, 2), (43, 8)]:
+        fullb, rays_b = rt.render(W, Hb, 5, 8, seed=9)
+        total = np.zeros_like(fullb)
+        n = 0
+        for r in range(world):
+            part, nr = rt.render(W, Hb, 5, 8, seed=9, band_first=r, band_stride=world)
+            rows = np.zeros(Hb, bool)
+            for b in range(r, (Hb + 7) // 8, world):
+                rows[8 * b:8 * b + 8] = True
+            assert (part[~rows] == 0).all() and (part[rows][..., 3] == 5).all()
+            total += part
+            n += nr
+        assert n == rays_b and O.same_values(total, fullb)
+    part, nr = rt.render(W, H, 4, 0, seed=9, band_first=1, band_stride=2)
+    assert nr == 0 and (part[8:16, :, 3] == 4).all() and (part[0:8] == 0).all() and (part[..., :3] == 0).all()
 
 
 def test_tonemap_matches_oracle(rt):
