@@ -4,7 +4,7 @@
  * reference has no FFI layer of its own: the path sits behind plain C++ free functions and
  * header-only classes (calc.h, hitPosition.h, shapes.h, camera.h) consumed by RayView. Every entry
  * point below therefore cites the reference interface it stands in for; the C++ mirror headers
- * under ray_amd/include/ (same names as the reference's) forward to these functions.
+ * under ray_amd/host/ (same names as the reference's) forward to these functions.
  *
  * Conventions
  *  - plain C, no C++/torch types; every function returns 0 on success, non-zero on error, and
@@ -13,7 +13,7 @@
  *    torch tensor's data_ptr()); everything else is host memory owned by the caller and may be
  *    freed as soon as the call returns.
  *  - one context per process and per GPU: rt_init(device) binds the context to a HIP device and
- *    creates the stream all kernels run on. Calls are blocking unless stated (rt_render_async).
+ *    creates the stream all kernels run on. Every call is blocking: it returns when its kernel has finished.
  *  - the library never falls back to the CPU: without a usable HIP device every compute entry
  *    point fails with an error.
  */
