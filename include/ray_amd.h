@@ -147,6 +147,15 @@ int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_cou
 int rt_render_bands(int w, int h, int band_first, int band_stride, int spp_begin, int spp_count, int depth,
                     uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
 
+/* RayView::renderOneRay (rayview.cpp:67-87) for a LIST of pixels: the reference's progressive view draws
+ * random pixels (randX, randY, rayview.cpp:69-70), renders numSamples samples of each and overwrites that
+ * pixel. d_pixels holds n pixel indices y * w + x (each in [0, w*h); the caller draws them, e.g. with
+ * calc::random_doubleW / H); every listed pixel gets samples [spp_begin, spp_begin + spp_count) exactly as
+ * rt_render computes them, its accumulator entry is overwritten (added to with RT_RENDER_ACCUMULATE), and
+ * no other pixel is touched. A pixel listed twice is rendered twice with the same result.               */
+int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_begin, int spp_count, int depth,
+                     uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
+
 /* Number of closest-hit scans of the last RT_RENDER_VERIFY render whose fast result (primitive or t
  * bits) differed from hitFromList's list-order loop (hitPosition.cpp:6-22) run on the same ray. No
  * counterpart in the reference: it checks the sphere filter of rt_scan.hpp at full frame sizes.     */

@@ -156,6 +156,23 @@ class Context:
         self._check(self.lib.rt_render(W, H, y_begin, H if y_count is None else y_count, spp_begin, spp, depth, seed, flags,
                                        _dev_ptr(accum), _dev_ptr(rays)))
 
+    def render_pixels(self, W, H, accum, pixels, spp, depth, seed=0, flags=0, spp_begin=0, rays=None):
+        """rt_render_pixels: `pixels` = int32 pixel indices y * W + x (numpy array, or a device buffer / torch tensor
+        with `n` given by its length) rendered into the caller-owned device accumulator."""
+        own = None
+        if isinstance(pixels, np.ndarray):
+            px = np.ascontiguousarray(pixels, dtype=np.int32)
+            n = int(px.size)
+            own = self.alloc(max(px.nbytes, 4)).from_numpy(px)
+            pixels = own
+        else:
+            n = int(pixels.numel()) if hasattr(pixels, "numel") else int(pixels.nbytes // 4)
+        try:
+            self._check(self.lib.rt_render_pixels(W, H, n, _dev_ptr(pixels), spp_begin, spp, depth, seed, flags, _dev_ptr(accum), _dev_ptr(rays)))
+        finally:
+            if own is not None:
+                own.free()
+
     def render(self, W, H, spp, depth, seed=0, flags=0, y_begin=0, y_count=None, spp_begin=0, band_first=0, band_stride=1):
         """Convenience: render into a fresh zeroed accumulator and return (accum[H,W,4], n_rays)."""
         acc = self.alloc(W * H * 16).zero()

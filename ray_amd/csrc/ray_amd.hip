@@ -526,6 +526,8 @@ struct RenderArgs {
     unsigned int* __restrict__ work_counter;       // next tile to hand out, zeroed before the launch
     unsigned long long* __restrict__ mismatches;   // VERIFY builds: scans whose fast result differs from the list-order scan
     unsigned long long* stamps;                    // RT_STAMPS diagnostic builds: [12] section cycles and pass counts
+    const int* __restrict__ pixels;                // PIXELS kernels: [n_pixels] pixel indices y * W + x to render
+    int n_pixels;
 };
 
 // Persistent waves with path regeneration. Every lane owns one pixel at a time and walks its samples
@@ -534,13 +536,15 @@ struct RenderArgs {
 // at, so the 64 lanes of a wave stay in the scan together instead of waiting for the longest path.
 // A lane whose pixel is finished takes the next pixel of the wave's tile queue; an empty queue is
 // refilled with one 8x8 tile from a global counter (one atomic per wave and tile).
-template <bool VERIFY>
+// PIXELS: the work items are the entries of a caller-supplied pixel list (RayView::renderOneRay's random
+// pixels, rayview.cpp:69-70) instead of the tiles of a row range.
+template <bool VERIFY, bool PIXELS = false>
 __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra) {
     __shared__ uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int tiles_x = (ra.W + kTile - 1) / kTile;
-    const int total = tiles_x * ra.tiles_y * 64;
+    const int total = PIXELS ? ra.n_pixels : tiles_x * ra.tiles_y * 64;
     __shared__ float4 s_stack[kLdsLevels * kBlock];
     PathStack st; st.lds = s_stack + threadIdx.x; st.base = ra.stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
     const bool normals = (ra.flags & RT_RENDER_NORMALS) != 0;
@@ -577,10 +581,18 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
             const int avail = q_end - q_cur;
             if (!have && rank < avail) {
                 const int idx = q_cur + rank;
-                const int tile = idx >> 6, in = idx & 63;
-                x = (tile % tiles_x) * kTile + (in & 7);
-                y = ra.y_begin + (ra.band_first + (tile / tiles_x) * ra.band_stride) * kTile + (in >> 3);
-                if (x < ra.W && y < ra.y_begin + ra.y_count) {
+                bool inside;
+                if (PIXELS) {
+                    inside = idx < total;
+                    const int p = inside ? ra.pixels[idx] : 0;
+                    y = p / ra.W; x = p - y * ra.W;
+                } else {
+                    const int tile = idx >> 6, in = idx & 63;
+                    x = (tile % tiles_x) * kTile + (in & 7);
+                    y = ra.y_begin + (ra.band_first + (tile / tiles_x) * ra.band_stride) * kTile + (in >> 3);
+                    inside = x < ra.W && y < ra.y_begin + ra.y_count;
+                }
+                if (inside) {
                     have = true; path = false;
                     pix = uint32_t(y) * uint32_t(ra.W) + uint32_t(x);
                     s = ra.spp_begin;
@@ -654,6 +666,18 @@ __global__ void render_black_kernel(int W, int y_begin, int y_count, int band_fi
     const int y = y_begin + (band_first + (r / kTile) * band_stride) * kTile + r % kTile;
     if (y >= y_begin + y_count) return;
     size_t pix = size_t(y) * W + x;
+    float4 a = make_float4(0.0f, 0.0f, 0.0f, float(spp_count));
+    if (flags & RT_RENDER_ACCUMULATE) {
+        float4 o = accum[pix];
+        a = make_float4(o.x + 0.0f, o.y + 0.0f, o.z + 0.0f, o.w + float(spp_count));
+    }
+    accum[pix] = a;
+}
+
+__global__ void render_black_pixels_kernel(int n, const int* __restrict__ pixels, int spp_count, uint32_t flags, float4* __restrict__ accum) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int pix = pixels[i];
     float4 a = make_float4(0.0f, 0.0f, 0.0f, float(spp_count));
     if (flags & RT_RENDER_ACCUMULATE) {
         float4 o = accum[pix];
@@ -1336,6 +1360,43 @@ int rt_render_bands(int w, int h, int band_first, int band_stride, int spp_begin
     const int n_bands = (h + kTile - 1) / kTile;
     const int mine = band_first >= n_bands ? 0 : (n_bands - band_first + band_stride - 1) / band_stride;
     return render_impl("rt_render_bands", w, h, 0, h, band_first, band_stride, mine, spp_begin, spp_count, depth, seed, flags, d_accum, d_rays);
+}
+
+// RayView::renderOneRay for a list of pixels (rayview.cpp:67-87): spp_count samples of each listed pixel,
+// the pixel's accumulator overwritten (or added to with RT_RENDER_ACCUMULATE), other pixels untouched.
+int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_begin, int spp_count, int depth, uint64_t seed, uint32_t flags,
+                     float* d_accum, uint64_t* d_rays) {
+    if (need_scene_cam()) return 1;
+    if (w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL) return fail("rt_render_pixels: bad size %dx%d", w, h);
+    if (n < 0 || n > 0x7fffffc0LL) return fail("rt_render_pixels: bad pixel count %lld", (long long)n);
+    if (spp_begin < 0 || spp_count < 0) return fail("rt_render_pixels: bad sample range [%d,+%d)", spp_begin, spp_count);
+    if (depth < 0 || depth > 128) return fail("rt_render_pixels: depth %d outside 0..128", depth);
+    if (!d_accum || (n > 0 && !d_pixels)) return fail("rt_render_pixels: null pointer");
+    if (flags & RT_RENDER_VERIFY) return fail("rt_render_pixels: RT_RENDER_VERIFY is an rt_render flag");
+    if (n == 0) { g.last_ms = 0; g.last_launches = 0; return 0; }
+    if (spp_count == 0 || depth == 0) {   // no ray is traced: every sample is black (calc.cpp:96-97)
+        HIP_OK(hipEventRecord(g.ev0, g.stream));
+        hipLaunchKernelGGL(render_black_pixels_kernel, dim3(int((n + 255) / 256)), dim3(256), 0, g.stream, int(n), d_pixels, spp_count, flags,
+                           reinterpret_cast<float4*>(d_accum));
+        return finish_timed(1);
+    }
+    const int resident = g.prop.multiProcessorCount * g.render_blocks_per_cu;
+    const int want = int((n + 255) / 256);
+    const int grid = want < resident ? want : resident;
+    if (ensure_stack(depth, grid)) return 1;
+    RenderArgs ra{};
+    ra.W = w; ra.H = h; ra.y_begin = 0; ra.y_count = h; ra.spp_begin = spp_begin; ra.spp_count = spp_count; ra.depth = depth;
+    ra.band_first = 0; ra.band_stride = 1; ra.tiles_y = 0;
+    ra.seed = seed; ra.flags = flags;
+    ra.accum = reinterpret_cast<float4*>(d_accum); ra.stack = static_cast<float4*>(g.stack);
+    ra.rays_out = reinterpret_cast<unsigned long long*>(d_rays);
+    ra.work_counter = static_cast<unsigned int*>(g.counters);
+    ra.mismatches = nullptr; ra.stamps = nullptr;
+    ra.pixels = d_pixels; ra.n_pixels = int(n);
+    HIP_OK(hipMemsetAsync(g.counters, 0, 4, g.stream));
+    HIP_OK(hipEventRecord(g.ev0, g.stream));
+    hipLaunchKernelGGL((render_kernel<false, true>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
+    return finish_timed(1);
 }
 
 #ifdef RT_STAMPS

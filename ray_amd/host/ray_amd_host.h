@@ -349,7 +349,19 @@ public:
                const QVector3D& background = img::gradientBgVec) {
         s_.upload(world, lights, background);
         rt_host::check(rt_set_camera(&cam.rt()));
+        rt_host::check(rt_memset(acc_.p, 0, uint64_t(w_) * h_ * 16));
         done_ = 0;
+    }
+    // RayView::go's own schedule (rayview.cpp:98-107): `pixels` holds the (randX, randY) draws of one tick as
+    // randY * width + randX; each listed pixel gets `samples` samples and its accumulator is overwritten, as
+    // renderOneRay + writeToImg do (rayview.cpp:67-87). `pass` selects the RNG streams of this tick.
+    void renderPixels(const std::vector<int32_t>& pixels, int samples, uint64_t pass = 0) {
+        if (pixels.empty()) return;
+        rt_host::DevBuf list(pixels.size() * 4);
+        rt_host::check(rt_memcpy_h2d(list.p, pixels.data(), pixels.size() * 4));
+        rt_host::check(rt_render_pixels(w_, h_, int64_t(pixels.size()), (const int32_t*)list.p, 0, samples, depth_, seed_ + pass, 0u,
+                                        (float*)acc_.p, nullptr));
+        if (done_ == 0) done_ = samples;   // image(): every pixel is normalised by its own sample count (accum.w)
     }
     // One time slice: passes until budget_ms of kernel time are used (at least one pass). Returns the
     // number of samples per pixel accumulated so far.

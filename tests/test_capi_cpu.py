@@ -55,6 +55,7 @@ def test_no_cpu_fallback_without_a_device(lib):
     assert lib.rt_upload_scene(sa.ref()) != 0
     assert lib.rt_render(8, 8, 0, 8, 0, 1, 4, 0, 0, None, None) != 0
     assert lib.rt_render_bands(8, 8, 0, 2, 0, 1, 4, 0, 0, None, None) != 0
+    assert lib.rt_render_pixels(8, 8, 1, None, 0, 1, 4, 0, 0, None, None) != 0
     assert b"rt_init" in lib.rt_last_error()
 
 

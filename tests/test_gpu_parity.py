@@ -221,6 +221,41 @@ def test_sample_and_row_splits_compose(rt):
     assert nr == 0 and (part[8:16, :, 3] == 4).all() and (part[0:8] == 0).all() and (part[..., :3] == 0).all()
 
 
+def test_render_pixels_equals_the_frame_at_those_pixels(rt):
+    """rt_render_pixels (RayView::renderOneRay for a list of random pixels, rayview.cpp:67-87): the listed
+    pixels get exactly the sums rt_render gives them, nothing else is touched; duplicates, a ragged count
+    (not a multiple of 64), accumulate, the black path and an empty list."""
+    sc = scenes.get_scene("random", half=4)
+    rt.upload_scene(sc)
+    W, H, spp, depth = 96, 54, 3, 8
+    full, _ = rt.render(W, H, spp, depth, seed=21)
+    ofull, _ = O.render(sc, W, H, spp, depth, rng_mode=1, seed64=21, math_mode=1)
+    assert O.same_values(full, ofull)
+    rng = np.random.default_rng(5)
+    px = rng.integers(0, W * H, 1000 + 37).astype(np.int32)     # with duplicates
+    acc = rt.alloc(W * H * 16).zero()
+    rays = rt.alloc(8).zero()
+    rt.render_pixels(W, H, acc, px, spp, depth, seed=21, rays=rays)
+    got = acc.to_numpy(np.float32, (H, W, 4)).reshape(-1, 4)
+    mask = np.zeros(W * H, bool); mask[px] = True
+    assert O.same_values(got[mask], full.reshape(-1, 4)[mask])
+    assert (got[~mask] == 0).all()
+    assert int(rays.to_numpy(np.uint64, (1,))[0]) > 0
+    # a second pass over other samples, accumulated: equals the 2-pass frame at those pixels
+    rt.render_pixels(W, H, acc, np.unique(px), 2, depth, seed=21, flags=1, spp_begin=spp)
+    two = rt.alloc(W * H * 16).zero()
+    rt.render_into(W, H, two, spp, depth, seed=21)
+    rt.render_into(W, H, two, 2, depth, seed=21, spp_begin=spp, flags=1)
+    got = acc.to_numpy(np.float32, (H, W, 4)).reshape(-1, 4)
+    assert O.same_values(got[mask], two.to_numpy(np.float32, (H, W, 4)).reshape(-1, 4)[mask])
+    # depth 0: black samples, no rays; empty list: nothing happens
+    acc.zero(); rays.zero()
+    rt.render_pixels(W, H, acc, px[:10], 4, 0, seed=21, rays=rays)
+    got = acc.to_numpy(np.float32, (H, W, 4)).reshape(-1, 4)
+    assert int(rays.to_numpy(np.uint64, (1,))[0]) == 0 and (got[px[:10], 3] == 4).all() and (got[:, :3] == 0).all()
+    rt.render_pixels(W, H, acc, np.zeros(0, np.int32), 4, 8, seed=21)
+
+
 def test_tonemap_matches_oracle(rt):
     import ctypes as C
     sc = scenes.builtin_scene()
