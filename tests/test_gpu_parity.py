@@ -491,3 +491,33 @@ def test_batch_boxes_edge_cases(rt):
     # duplicates: some winning index must be one of the appended copies (ties go to the later entry)
     first_dup = 1 + len(centres) + len(grid)
     assert (rt.hit_rays(ro, rd, 0.001, np.inf)[0] > first_dup).any()
+
+
+@pytest.mark.parametrize("n_sph", [15, 16, 17, 31, 33, 63, 65, 129, 513, 1025, 3000])
+def test_group_layout_sizes(rt, n_sph):
+    """Sphere counts around every padding boundary of the scan's layout (16-item batches, 4-batch words,
+    16-word chunks, the 16-item minimum of the filter group), mixed radii with a few huge / far spheres that
+    go to the exact group: hitFromList equals the oracle's loop for random and for targeted rays."""
+    rng = np.random.default_rng(1000 + n_sph)
+    mats = [scenes.Material(scenes.MAT_LAMBERTIAN, (0.5, 0.5, 0.5))]
+    c = rng.uniform(-10, 10, (n_sph, 3))
+    r = np.exp(rng.uniform(np.log(0.02), np.log(0.8), n_sph))
+    big = rng.random(n_sph) < 0.03
+    r[big] *= 200.0
+    c[big] *= 30.0
+    shapes = [scenes.Shape("sphere", (float(np.float32(c[i, 0])), float(np.float32(c[i, 1])), float(np.float32(c[i, 2])), float(np.float32(r[i]))), 0)
+              for i in range(n_sph)]
+    sc = scenes.Scene(mats, shapes, None, scenes.rayview_camera())
+    rt.upload_scene(sc, set_camera=False)
+    n = 6000
+    pick = rng.integers(0, n_sph, n)
+    target = c[pick] + rng.uniform(-1, 1, (n, 3)) * r[pick, None]
+    ro = rng.uniform(-25, 25, (n, 3))
+    rd = target - ro
+    rd[: n // 3] = rng.standard_normal((n // 3, 3))
+    ro, rd = ro.astype(np.float32), rd.astype(np.float32)
+    got = rt.hit_rays(ro, rd, 0.001, np.inf)
+    ref = O.hit_rays(sc, ro, rd, 0.001, np.inf)
+    assert np.array_equal(got[0], ref[0])
+    assert O.bits_equal(got[1], ref[1])
+    assert (got[0] >= 0).mean() > 0.3
