@@ -142,6 +142,7 @@ def test_radiance_sums_bit_exact_vs_oracle(rt, name, kw, W, H, spp, depth):
     ("random", {"half": 11}, 960, 540, 4, 8),
     ("builtin", {}, 640, 360, 8, 10),
     ("mixed", {"half": 5, "n": 9}, 320, 180, 2, 8),
+    ("tris", {"n": 71}, 480, 270, 2, 8),          # 9800 triangles: 10 chunks of the triangle group
 ])
 def test_fast_scan_equals_list_order_scan_at_scale(rt, name, kw, W, H, spp, depth):
     """RT_RENDER_VERIFY: every closest-hit scan of the frame (millions of primary and bounce rays) is
@@ -520,4 +521,41 @@ def test_group_layout_sizes(rt, n_sph):
     ref = O.hit_rays(sc, ro, rd, 0.001, np.inf)
     assert np.array_equal(got[0], ref[0])
     assert O.bits_equal(got[1], ref[1])
+    assert (got[0] >= 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("n_tri", [1, 31, 33, 257, 1023, 1100, 2500])
+def test_triangle_group_layout_sizes(rt, n_tri):
+    """Triangle soups (single-triangle items and quad halves that share an item, sizes around the batch /
+    word / chunk boundaries of the triangle group, a few huge triangles for the exact group): hitFromList
+    through boxes + item flags + Moeller-Trumbore equals the oracle's loop."""
+    rng = np.random.default_rng(2000 + n_tri)
+    mats = [scenes.Material(scenes.MAT_LAMBERTIAN, (0.5, 0.5, 0.5))]
+    shapes = []
+    cents = []
+    while len(shapes) < n_tri:
+        p = rng.uniform(-10, 10, 3)
+        e1, e2 = rng.standard_normal(3) * 0.5, rng.standard_normal(3) * 0.5
+        if rng.random() < 0.02:
+            e1 *= 100.0; e2 *= 100.0
+        v = [np.float32(p), np.float32(p + e1), np.float32(p + e2), np.float32(p + e1 + e2)]
+        shapes.append(scenes.Shape("triangle", tuple(float(t) for t in (*v[0], *v[1], *v[2])), 0))
+        cents.append((v[0] + v[1] + v[2]) / 3)
+        if rng.random() < 0.5 and len(shapes) < n_tri:     # the other half of the quad, consecutive in the list
+            shapes.append(scenes.Shape("triangle", tuple(float(t) for t in (*v[2], *v[1], *v[3])), 0))
+            cents.append((v[2] + v[1] + v[3]) / 3)
+    sc = scenes.Scene(mats, shapes, None, scenes.rayview_camera())
+    rt.upload_scene(sc, set_camera=False)
+    n = 6000
+    cents = np.array(cents, np.float64)
+    pick = rng.integers(0, n_tri, n)
+    ro = rng.uniform(-20, 20, (n, 3))
+    rd = cents[pick] + rng.uniform(-0.2, 0.2, (n, 3)) - ro
+    rd[: n // 4] = rng.standard_normal((n // 4, 3))
+    ro, rd = ro.astype(np.float32), rd.astype(np.float32)
+    for t_min, t_max in [(0.001, np.inf), (-3.0, 40.0)]:
+        got = rt.hit_rays(ro, rd, t_min, t_max)
+        ref = O.hit_rays(sc, ro, rd, t_min, t_max)
+        assert np.array_equal(got[0], ref[0])
+        assert O.bits_equal(got[1], ref[1])
     assert (got[0] >= 0).mean() > 0.3
