@@ -139,6 +139,8 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # communicator set-up (RCCL creates its rings on the first collective) is not part of a frame
+        dist.all_reduce(torch.zeros(1, dtype=torch.float32, device=dev))
 
     wl = dict(WORKLOADS[args.workload])
     if args.spp:
