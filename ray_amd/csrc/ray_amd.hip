@@ -167,6 +167,38 @@ __device__ __forceinline__ void scan_rects(const double* __restrict__ rect, cons
     }
 }
 
+// The same enclosure test for scenes with many rects (box_scene: 156), as a flag pass: one bit per rect and
+// lane (rect j <-> bit 31 - j % 32 of word j / 32 of the chunk), so that the reference's FP64 test runs in a
+// per-lane walk over the lane's own flagged rects instead of for every rect that ANY lane of the wave
+// cannot exclude. `cur` carries the word under construction from one axis loop to the next.
+template <int AXIS>
+__device__ __forceinline__ void flag_rects(const float* __restrict__ rect_f, int j0, int j1, int chunk0, const Ray& r, float tminf, float btf,
+                                           uint32_t& cur, uint32_t& summary, uint32_t* words) {
+    const float ok = AXIS == 0 ? r.o.z : (AXIS == 1 ? r.o.y : r.o.x), dk = AXIS == 0 ? r.d.z : (AXIS == 1 ? r.d.y : r.d.x);
+    const float oa = AXIS == 2 ? r.o.y : r.o.x, da = AXIS == 2 ? r.d.y : r.d.x;
+    const float ob = AXIS == 0 ? r.o.y : r.o.z, db = AXIS == 0 ? r.d.y : r.d.z;
+    const float idk = __builtin_amdgcn_rcpf(dk);
+    cfp f = (cfp)(uintptr_t)rect_f;
+    for (int j = j0; j < j1; ++j) {
+        const float kf = f[5 * j], a0 = f[5 * j + 1], a1 = f[5 * j + 2], b0 = f[5 * j + 3], b1 = f[5 * j + 4];
+        const float tf = (kf - ok) * idk;
+        const float et = ((__builtin_fabsf(kf) + __builtin_fabsf(ok)) * __builtin_fabsf(idk) + __builtin_fabsf(tf)) * 1.0e-6f;
+        const float pa = tf * da, pb = tf * db;
+        const float af = oa + pa, bf = ob + pb;
+        const float ea = et * __builtin_fabsf(da) + (__builtin_fabsf(oa) + __builtin_fabsf(pa)) * 1.0e-6f;
+        const float eb = et * __builtin_fabsf(db) + (__builtin_fabsf(ob) + __builtin_fabsf(pb)) * 1.0e-6f;
+        const bool out = tf - et > btf || tf + et < tminf || af + ea < a0 || af - ea > a1 || bf + eb < b0 || bf - eb > b1;
+        cur = (cur << 1) | (out ? 0u : 1u);
+        if (((j - chunk0) & 31) == 31) {
+            const int wi = (j - chunk0) >> 5;
+            words[wi * kScanBlock] = cur;
+            summary |= (cur != 0u ? 1u : 0u) << wi;
+            cur = 0u;
+        }
+    }
+}
+constexpr int kRectFlagMin = 16;   // fewer rects: the direct loop of scan_rects
+
 // Triangle (not in the reference; DESIGN.md "triangles"): Moeller-Trumbore, FP32, NaN = miss.
 RT_DEV bool tri_t(const Ray& r, const float* __restrict__ q, double t_min, double bt, int idx, int bi, double* t_out) {
     V3 v0 = v3(q[0], q[1], q[2]), e1 = v3(q[3], q[4], q[5]), e2 = v3(q[6], q[7], q[8]);
@@ -243,6 +275,11 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
 // Fast scan: spheres through rt_scan.hpp (filter + exact), then rects and triangles. Lanes whose ray
 // is outside the fast range (non-finite, huge, zero direction), a scene that is, or a NaN t from a
 // rect, fall back to the list-order scan, which is the reference loop itself.
+// RECTS: 0 = the rects through the direct loop (scan_rects), 1 = through the flag pass + walk (flag_rects; the
+// launcher picks this instance for scenes with >= kRectFlagMin rects), 2 = choose at run time (the one-ray kernels).
+// A compile-time choice for the render kernel: the second path's code costs the 485-sphere frame 3 % when it is
+// merely present.
+template <int RECTS = 2>
 __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, double t_min, double t_max, uint32_t* words RT_STAMP_PARAM) {
     Hit h; h.t = t_max; h.prim = -1;
     bool ok = sc.fast_ok && ray_in_fast_range(r.o, r.d, r.dl2) && t_min == t_min && t_max == t_max;
@@ -252,7 +289,41 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
         scan_spheres(sc.sg, sc.sph_prim, r.o, r.d, r.dl2, t_min, t_max, hs, words RT_STAMP_ARG);
         h.t = hs.bt; h.prim = hs.idx;
         bool saw_nan = false;
-        if (sc.n_rect > 0) {
+        if (RECTS == 1 || (RECTS == 2 && sc.n_rect >= kRectFlagMin)) {
+            const float tminf = __double2float_rd(t_min);
+            const int e0 = sc.n_rect_xy, e1 = sc.n_rect_xy + sc.n_rect_xz;
+            for (int c0 = 0; c0 < sc.n_rect; c0 += 32 * kMaskWords) {
+                const int c1 = c0 + 32 * kMaskWords < sc.n_rect ? c0 + 32 * kMaskWords : sc.n_rect;
+                const float btf = __double2float_ru(h.t);
+                uint32_t cur = 0u, summary = 0u;
+                flag_rects<0>(sc.rect_f, c0 < e0 ? c0 : e0, c1 < e0 ? c1 : e0, c0, r, tminf, btf, cur, summary, words);
+                flag_rects<1>(sc.rect_f, c0 > e0 ? (c0 < e1 ? c0 : e1) : e0, c1 < e1 ? (c1 > e0 ? c1 : e0) : e1, c0, r, tminf, btf, cur, summary, words);
+                flag_rects<2>(sc.rect_f, c0 > e1 ? c0 : e1, c1 > e1 ? c1 : e1, c0, r, tminf, btf, cur, summary, words);
+                if (((c1 - c0) & 31) != 0) {                       // the last, partial word
+                    const int wi = (c1 - c0) >> 5;
+                    cur <<= 32 - ((c1 - c0) & 31);
+                    words[wi * kScanBlock] = cur;
+                    summary |= (cur != 0u ? 1u : 0u) << wi;
+                }
+                RT_STAMP(4);
+                walk_flagged(summary, c0 >> 5, words, [&](int j) {
+                    // the ray's components along the rect's normal and in its plane, picked with bit masks: a select
+                    // chain over ray components is turned into an indexed load from a scratch copy of the ray
+                    uint32_t mxy = j < e0 ? 0xffffffffu : 0u, mxz = j < e1 ? 0xffffffffu : 0u;
+                    asm("" : "+v"(mxy), "+v"(mxz));
+                    auto pick = [](uint32_t m, float a, float b) { return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m)); };
+                    const float ok = pick(mxy, r.o.z, pick(mxz, r.o.y, r.o.x)), dk = pick(mxy, r.d.z, pick(mxz, r.d.y, r.d.x));
+                    const float oa = pick(mxz, r.o.x, r.o.y), da = pick(mxz, r.d.x, r.d.y);
+                    const float ob = pick(mxy, r.o.y, r.o.z), db = pick(mxy, r.d.y, r.d.z);
+                    const double* q = sc.rect + 5 * j;
+                    const int idx = sc.rect_prim[j];
+                    double t;
+                    if (rect_core(ok, dk, oa, da, ob, db, q[0], q[1], q[2], q[3], q[4], t_min, h.t, idx, h.prim, &t)) {
+                        if (t != t) saw_nan = true; else { h.t = t; h.prim = idx; }
+                    }
+                } RT_STAMP_ARG);
+            }
+        } else if (RECTS != 1 && sc.n_rect > 0) {
             const float tminf = __double2float_rd(t_min);
             float btf = __double2float_ru(h.t);
             scan_rects<0>(sc.rect, sc.rect_f, sc.rect_prim, 0, sc.n_rect_xy, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
@@ -538,7 +609,7 @@ struct RenderArgs {
 // refilled with one 8x8 tile from a global counter (one atomic per wave and tile).
 // PIXELS: the work items are the entries of a caller-supplied pixel list (RayView::renderOneRay's random
 // pixels, rayview.cpp:69-70) instead of the tiles of a row range.
-template <bool VERIFY, bool PIXELS = false>
+template <bool VERIFY, bool PIXELS = false, int RECTS = 0>
 __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra) {
     __shared__ uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
@@ -616,7 +687,7 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
         // ---- one closest-hit scan per lane, then one bounce ------------------------------------------------
         if (path) {
             ++n_rays;
-            Hit h = closest_hit(sc, ray, double(0.001f), kInf, words RT_STAMP_ARG);   // calc.cpp:99
+            Hit h = closest_hit<RECTS>(sc, ray, double(0.001f), kInf, words RT_STAMP_ARG);   // calc.cpp:99
             if (VERIFY) {
                 Hit h2 = closest_hit_listorder(sc, ray, double(0.001f), kInf);
                 if (h2.prim != h.prim || __double_as_longlong(h2.t) != __double_as_longlong(h.t)) atomicAdd(ra.mismatches, 1ull);
@@ -971,7 +1042,7 @@ int rt_init(int device) {
     HIP_OK(hipMalloc(&g.counters, 128));
     HIP_OK(hipMemset(g.counters, 0, 128));
     int per_cu = 0;
-    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false>, kBlock, 0));
+    HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, false, 0>, kBlock, 0));
     g.render_blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
     g.device = device;
     g.ready = true;
@@ -1338,8 +1409,11 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     HIP_OK(hipMemsetAsync(g.counters, 0, verify ? 16 : 4, g.stream));
 #endif
     HIP_OK(hipEventRecord(g.ev0, g.stream));
-    if (verify) hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
-    else hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
+    const bool many_rects = g.scene.n_rect >= kRectFlagMin;
+    if (verify && many_rects) hipLaunchKernelGGL((render_kernel<true, false, 1>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
+    else if (verify) hipLaunchKernelGGL((render_kernel<true, false, 0>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
+    else if (many_rects) hipLaunchKernelGGL((render_kernel<false, false, 1>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
+    else hipLaunchKernelGGL((render_kernel<false, false, 0>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
     return finish_timed(1);
 }
 
@@ -1395,7 +1469,8 @@ int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_b
     ra.pixels = d_pixels; ra.n_pixels = int(n);
     HIP_OK(hipMemsetAsync(g.counters, 0, 4, g.stream));
     HIP_OK(hipEventRecord(g.ev0, g.stream));
-    hipLaunchKernelGGL((render_kernel<false, true>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
+    if (g.scene.n_rect >= kRectFlagMin) hipLaunchKernelGGL((render_kernel<false, true, 1>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
+    else hipLaunchKernelGGL((render_kernel<false, true, 0>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
     return finish_timed(1);
 }
 
