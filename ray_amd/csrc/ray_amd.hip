@@ -51,6 +51,8 @@ struct DevScene {
     float bg[3];
     FilterGroup sg, tg;                    // exact / filter partition of the sphere and triangle slots (rt_scan.hpp)
     int fast_ok;                           // 0: a primitive is non-finite / out of range -> list-order scan only
+    const float* __restrict__ rect_box;    // [12 per pair of rects] lo x (rect 0, rect 1), lo y, lo z, hi x, hi y, hi z, rounded outwards
+    float rect_extent;                     // max |coordinate| of the rects
 };
 
 struct DevCamera {
@@ -167,35 +169,35 @@ __device__ __forceinline__ void scan_rects(const double* __restrict__ rect, cons
     }
 }
 
-// The same enclosure test for scenes with many rects (box_scene: 156), as a flag pass: one bit per rect and
-// lane (rect j <-> bit 31 - j % 32 of word j / 32 of the chunk), so that the reference's FP64 test runs in a
-// per-lane walk over the lane's own flagged rects instead of for every rect that ANY lane of the wave
-// cannot exclude. `cur` carries the word under construction from one axis loop to the next.
-template <int AXIS>
-__device__ __forceinline__ void flag_rects(const float* __restrict__ rect_f, int j0, int j1, int chunk0, const Ray& r, float tminf, float btf,
-                                           uint32_t& cur, uint32_t& summary, uint32_t* words) {
-    const float ok = AXIS == 0 ? r.o.z : (AXIS == 1 ? r.o.y : r.o.x), dk = AXIS == 0 ? r.d.z : (AXIS == 1 ? r.d.y : r.d.x);
-    const float oa = AXIS == 2 ? r.o.y : r.o.x, da = AXIS == 2 ? r.d.y : r.d.x;
-    const float ob = AXIS == 0 ? r.o.y : r.o.z, db = AXIS == 0 ? r.d.y : r.d.z;
-    const float idk = __builtin_amdgcn_rcpf(dk);
-    cfp f = (cfp)(uintptr_t)rect_f;
-    for (int j = j0; j < j1; ++j) {
-        const float kf = f[5 * j], a0 = f[5 * j + 1], a1 = f[5 * j + 2], b0 = f[5 * j + 3], b1 = f[5 * j + 4];
-        const float tf = (kf - ok) * idk;
-        const float et = ((__builtin_fabsf(kf) + __builtin_fabsf(ok)) * __builtin_fabsf(idk) + __builtin_fabsf(tf)) * 1.0e-6f;
-        const float pa = tf * da, pb = tf * db;
-        const float af = oa + pa, bf = ob + pb;
-        const float ea = et * __builtin_fabsf(da) + (__builtin_fabsf(oa) + __builtin_fabsf(pa)) * 1.0e-6f;
-        const float eb = et * __builtin_fabsf(db) + (__builtin_fabsf(ob) + __builtin_fabsf(pb)) * 1.0e-6f;
-        const bool out = tf - et > btf || tf + et < tminf || af + ea < a0 || af - ea > a1 || bf + eb < b0 || bf - eb > b1;
-        cur = (cur << 1) | (out ? 0u : 1u);
-        if (((j - chunk0) & 31) == 31) {
-            const int wi = (j - chunk0) >> 5;
+// Scenes with many rects (box_scene: 156): a flag pass, one bit per rect and lane (rect j <-> bit 31 - j % 32 of
+// word j / 32 of the chunk), then a per-lane walk that runs the reference's FP64 test on the lane's own flagged
+// rects only. The flag is the slab test of rt_scan.hpp on the rect as a box of zero thickness, two rects per
+// packed operation, widened by m = 2e-5 (|o| + extent of the rects): the reference's hit point lies on the rect
+// up to FP64 rounding, the FP32 slab arithmetic moves a plane by < 3e-7 (|o| + extent) and the clamp of a tiny
+// direction component moves the ray by less than that inside the scene. Axis-parallel rays (a direction
+// component exactly 0, where the reference's plane distance is inf or NaN and list order decides) do not come here.
+__device__ __forceinline__ uint32_t flag_rects(const DevScene& sc, const FilterRay& br, float t_hi, int c0, int c1, uint32_t* words) {
+    cf2p rb = RT_CONST_F2(sc.rect_box);
+    uint32_t cur = 0u, summary = 0u;
+    for (int p = c0 >> 1; 2 * p < c1; ++p) {
+        bool n0, n1;
+        box_pair(br, t_hi, rb[6 * p], rb[6 * p + 1], rb[6 * p + 2], rb[6 * p + 3], rb[6 * p + 4], rb[6 * p + 5], n0, n1);
+        cur = (cur << 2) | (n0 ? 2u : 0u) | (n1 && 2 * p + 1 < c1 ? 1u : 0u);
+        if ((p & 15) == 15) {
+            const int wi = (2 * p - c0) >> 5;
             words[wi * kScanBlock] = cur;
             summary |= (cur != 0u ? 1u : 0u) << wi;
             cur = 0u;
         }
     }
+    const int done = ((c1 - c0 + 1) >> 1) & 15;          // pairs in the last, partial word
+    if (done != 0) {
+        const int wi = (c1 - c0 - 1) >> 5;
+        cur <<= 32 - 2 * done;
+        words[wi * kScanBlock] = cur;
+        summary |= (cur != 0u ? 1u : 0u) << wi;
+    }
+    return summary;
 }
 constexpr int kRectFlagMin = 16;   // fewer rects: the direct loop of scan_rects
 
@@ -290,21 +292,14 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
         h.t = hs.bt; h.prim = hs.idx;
         bool saw_nan = false;
         if (RECTS == 1 || (RECTS == 2 && sc.n_rect >= kRectFlagMin)) {
-            const float tminf = __double2float_rd(t_min);
             const int e0 = sc.n_rect_xy, e1 = sc.n_rect_xy + sc.n_rect_xz;
-            for (int c0 = 0; c0 < sc.n_rect; c0 += 32 * kMaskWords) {
+            if (r.d.x == 0.0f || r.d.y == 0.0f || r.d.z == 0.0f) saw_nan = true;   // axis-parallel: the list-order loop
+            FilterRay br;
+            const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(r.o.x), __builtin_fabsf(r.o.y)), __builtin_fabsf(r.o.z));
+            set_box_ray(br, r.o, r.d, r.dl2, 2.0e-5f * (omax + sc.rect_extent) + 1.0e-30f, t_min);
+            for (int c0 = 0; c0 < sc.n_rect && !saw_nan; c0 += 32 * kMaskWords) {
                 const int c1 = c0 + 32 * kMaskWords < sc.n_rect ? c0 + 32 * kMaskWords : sc.n_rect;
-                const float btf = __double2float_ru(h.t);
-                uint32_t cur = 0u, summary = 0u;
-                flag_rects<0>(sc.rect_f, c0 < e0 ? c0 : e0, c1 < e0 ? c1 : e0, c0, r, tminf, btf, cur, summary, words);
-                flag_rects<1>(sc.rect_f, c0 > e0 ? (c0 < e1 ? c0 : e1) : e0, c1 < e1 ? (c1 > e0 ? c1 : e0) : e1, c0, r, tminf, btf, cur, summary, words);
-                flag_rects<2>(sc.rect_f, c0 > e1 ? c0 : e1, c1 > e1 ? c1 : e1, c0, r, tminf, btf, cur, summary, words);
-                if (((c1 - c0) & 31) != 0) {                       // the last, partial word
-                    const int wi = (c1 - c0) >> 5;
-                    cur <<= 32 - ((c1 - c0) & 31);
-                    words[wi * kScanBlock] = cur;
-                    summary |= (cur != 0u ? 1u : 0u) << wi;
-                }
+                const uint32_t summary = flag_rects(sc, br, __double2float_ru(h.t), c0, c1, words);
                 RT_STAMP(4);
                 walk_flagged(summary, c0 >> 5, words, [&](int j) {
                     // the ray's components along the rect's normal and in its plane, picked with bit masks: a select
@@ -1243,12 +1238,32 @@ int rt_upload_scene(const RtScene* s) {
         }
     }
 
+    std::vector<float> rect_box(((rect_axis.size() + 1) / 2) * 12, 0.0f);
+    float rect_extent = 0.0f;
+    for (size_t j = 0; j < rect_axis.size(); ++j) {
+        const float* f = &rect_f[5 * j];   // k nearest, a0 down, a1 up, b0 down, b1 up
+        const double k = rect[5 * j + 4];
+        for (int c = 0; c < 5; ++c) if (!(std::fabs(rect[5 * j + c]) <= 1.0e7)) finite = false;   // inf / NaN / huge: list-order scan only
+        const float kd = double(f[0]) > k ? std::nextafterf(f[0], -INFINITY) : f[0], ku = double(f[0]) < k ? std::nextafterf(f[0], INFINITY) : f[0];
+        float lo[3], hi[3];
+        const int ax = rect_axis[j];       // 0: XY (z = k; a = x, b = y), 1: XZ (y = k; a = x, b = z), 2: YZ (x = k; a = y, b = z)
+        if (ax == 0) { lo[0] = f[1]; hi[0] = f[2]; lo[1] = f[3]; hi[1] = f[4]; lo[2] = kd; hi[2] = ku; }
+        else if (ax == 1) { lo[0] = f[1]; hi[0] = f[2]; lo[2] = f[3]; hi[2] = f[4]; lo[1] = kd; hi[1] = ku; }
+        else { lo[1] = f[1]; hi[1] = f[2]; lo[2] = f[3]; hi[2] = f[4]; lo[0] = kd; hi[0] = ku; }
+        float* q = &rect_box[(j / 2) * 12];
+        for (int c = 0; c < 3; ++c) {
+            q[2 * c + j % 2] = lo[c]; q[6 + 2 * c + j % 2] = hi[c];
+            rect_extent = std::max(rect_extent, std::max(std::fabs(lo[c]), std::fabs(hi[c])));
+        }
+    }
+    if (!(rect_extent <= 1.0e7f)) finite = false;
+
     HIP_OK(hipStreamSynchronize(g.stream));
     free_scene();
     DevScene ds{};
-    ds.n_rect_xy = n_rect_axis[0]; ds.n_rect_xz = n_rect_axis[1];
+    ds.n_rect_xy = n_rect_axis[0]; ds.n_rect_xz = n_rect_axis[1]; ds.rect_extent = rect_extent;
     ds.n_sph = int(sph.size()); ds.n_rect = int(rect_axis.size()); ds.n_tri = int(tri_prim.size()); ds.n_prims = s->n_prims;
-    if (upload(sph, &ds.sph) || upload(sph_prim, &ds.sph_prim) || upload(rect, &ds.rect) || upload(rect_f, &ds.rect_f) || upload(rect_axis, &ds.rect_axis) ||
+    if (upload(sph, &ds.sph) || upload(sph_prim, &ds.sph_prim) || upload(rect, &ds.rect) || upload(rect_f, &ds.rect_f) || upload(rect_box, &ds.rect_box) || upload(rect_axis, &ds.rect_axis) ||
         upload(rect_prim, &ds.rect_prim) || upload(tri, &ds.tri) || upload(tri_prim, &ds.tri_prim) ||
         upload(prim_kind, &ds.prim_kind) || upload(prim_local, &ds.prim_local) || upload(prim_mat, &ds.prim_mat))
         return 1;

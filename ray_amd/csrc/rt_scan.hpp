@@ -216,6 +216,19 @@ struct FilterRay {
     f2 I01, I2, CX, CY, CZ;      // (inv.x, inv.y), (inv.z, -), (c_lo, c_hi) per axis
     float t_lo;
 };
+// Slab-test constants (box_pair) of the ray o + t d, o given relative to the boxes' reference point: the boxes are
+// widened by m; direction components below 1e-7 |d| are clamped
+__device__ __forceinline__ void set_box_ray(FilterRay& fr, V3 orel, V3 d, float a, float m, double t_min) {
+    const float dmin = 1.0e-7f * __builtin_amdgcn_sqrtf(a);
+    const float ix = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.x), dmin), d.x));
+    const float iy = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.y), dmin), d.y));
+    const float iz = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.z), dmin), d.z));
+    fr.I01 = f2{ix, iy}; fr.I2 = f2{iz, 0.0f};
+    fr.CX = f2{-(orel.x + m) * ix, -(orel.x - m) * ix};
+    fr.CY = f2{-(orel.y + m) * iy, -(orel.y - m) * iy};
+    fr.CZ = f2{-(orel.z + m) * iz, -(orel.z - m) * iz};
+    fr.t_lo = t_min >= 0.0 ? 0.0f : -__builtin_inff();
+}
 __device__ __forceinline__ FilterRay filter_ray(const FilterGroup& fg, V3 o, V3 d, float a, float ia, double t_min) {
     FilterRay fr;
     if (fg.n_fpairs == 0) {   // wave-uniform: only always-flagged pairs, the constants are not read
