@@ -559,3 +559,55 @@ def test_triangle_group_layout_sizes(rt, n_tri):
         assert np.array_equal(got[0], ref[0])
         assert O.bits_equal(got[1], ref[1])
     assert (got[0] >= 0).mean() > 0.3
+
+
+@pytest.mark.parametrize("n_rect", [15, 16, 17, 33, 160, 513, 1030])
+def test_rect_flag_pass_sizes_and_edge_rays(rt, n_rect):
+    """Rect soups around the boundaries of the rect flag pass (16-rect batches, 32-rect words, 512-rect chunks;
+    below 16 the direct loop runs), all three orientations, some rects duplicated later in the list (ties go to
+    the later entry). Rays: random, aimed at rect corners and edges (points on the boundary itself), starting ON
+    a rect, axis-parallel with +-0 components (the reference's inf / NaN plane distances: list-order loop),
+    negative t_min and finite t_max."""
+    rng = np.random.default_rng(3000 + n_rect)
+    mats = [scenes.Material(scenes.MAT_LAMBERTIAN, (0.5, 0.5, 0.5))]
+    kinds = ["xy_rect", "xz_rect", "yz_rect"]
+    shapes, geo = [], []
+    while len(shapes) < n_rect:
+        if geo and rng.random() < 0.1:
+            kind, q = geo[rng.integers(0, len(geo))]                      # an exact duplicate
+        else:
+            kind = int(rng.integers(0, 3))
+            a0, b0 = rng.uniform(-10, 10, 2)
+            q = (float(np.float32(a0)), float(np.float32(a0 + rng.uniform(0.1, 4.0))), float(np.float32(b0)),
+                 float(np.float32(b0 + rng.uniform(0.1, 4.0))), float(np.float32(rng.uniform(-10, 10))))
+        geo.append((kind, q))
+        shapes.append(scenes.Shape(kinds[kind], q, 0))
+    sc = scenes.Scene(mats, shapes, None, scenes.rayview_camera())
+    rt.upload_scene(sc, set_camera=False)
+
+    def point_on(kind, q, fa, fb):
+        a, b = q[0] + fa * (q[1] - q[0]), q[2] + fb * (q[3] - q[2])
+        return [(a, b, q[4]), (a, q[4], b), (q[4], a, b)][kind]
+    n = 8000
+    pick = rng.integers(0, n_rect, n)
+    frac = rng.choice([0.0, 1.0, 0.5, -1e-7, 1.0 + 1e-7, 0.3], (n, 2))    # corners, edges, just outside, inside
+    target = np.array([point_on(*geo[pick[i]], frac[i, 0], frac[i, 1]) for i in range(n)])
+    ro = rng.uniform(-14, 14, (n, 3))
+    rd = target - ro
+    k4 = n // 4
+    rd[:k4] = rng.standard_normal((k4, 3))                                # random directions
+    ro[k4:k4 + 500] = target[k4:k4 + 500]                                 # origin ON a rect
+    rd[k4:k4 + 500] = rng.standard_normal((500, 3))
+    ax = rng.integers(0, 3, 600)                                          # axis-parallel rays, both signs of zero
+    rd[-600:] = rng.standard_normal((600, 3))
+    rd[np.arange(n - 600, n), ax] = rng.choice([0.0, -0.0], 600)
+    rd[-200:, (ax[-200:] + 1) % 3] = 0.0
+    rd[(rd == 0).all(1)] = (0.0, 1.0, 0.0)
+    ro, rd = ro.astype(np.float32), rd.astype(np.float32)
+    for t_min, t_max in [(0.001, np.inf), (-2.0, 9.0)]:
+        got = rt.hit_rays(ro, rd, t_min, t_max)
+        ref = O.hit_rays(sc, ro, rd, t_min, t_max)
+        assert np.array_equal(got[0], ref[0]), np.flatnonzero(got[0] != ref[0])[:10]
+        for a, b in zip(got[1:], ref[1:]):
+            assert O.same_values(a, b)
+    assert (got[0] >= 0).mean() > 0.3
