@@ -20,7 +20,7 @@ for spec in sys.argv[1:] or ["c3:256", "c2:64", "box:64", "c4:4", "c5:2"]:
     acc = ctx.alloc(W * H * 16).zero()
     rays = ctx.alloc(8).zero()
     t0 = time.time()
-    ctx.render_into(W, H, acc, spp, wl["depth"], seed=0xC0FFEE, rays=rays, flags=api.RENDER_VERIFY)
+    ctx.render_into(W, H, acc, spp, wl["depth"], seed=int(os.environ.get('RT_VERIFY_SEED', '0xC0FFEE'), 0), rays=rays, flags=api.RENDER_VERIFY)
     n = int(rays.to_numpy("uint64", (1,))[0])
     print(f"{wl['desc']} at {spp} spp: {n} rays verified against the list-order loop, {ctx.verify_mismatches()} mismatches ({time.time() - t0:.1f} s)", flush=True)
     acc.free(); rays.free()
