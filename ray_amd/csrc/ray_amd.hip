@@ -259,7 +259,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     const FilterGroup& tg = sc.tg;
     if (tg.n_epairs == 0 && tg.n_fpairs == 0) return;
     auto visit = [&](int item) {       // an item: up to two triangles under one bounding sphere
-#pragma unroll 1
+#pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             const int slot = 2 * item + hh;
             const int idx = sc.tri_prim[slot];
