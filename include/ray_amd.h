@@ -139,6 +139,19 @@ int rt_hit_rays(int64_t n, const float* d_origin, const float* d_dir, double t_m
 int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth,
               uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
 
+/* rt_render for callers that cannot allocate device memory. NO COUNTERPART IN THE REFERENCE: it exists for
+ * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc. Same arguments, same
+ * kernels and bit-identical results as rt_render, but the kernel's scratch (the tile counter and the HBM part
+ * of the per-thread path stack, which rt_render keeps in buffers it allocates and grows on demand) lives in a
+ * file-scope device array of the library: 40 MiB + 256 B on every GPU the library is bound to, held until the
+ * process ends. The call makes no hipMalloc / hipFree and calls no allocating routine.
+ * Limits: depth <= 16 (RT_NOALLOC_MAX_DEPTH; deeper paths are rejected with an error, use rt_render);
+ * RT_RENDER_VERIFY is rejected. Every call on one GPU shares that GPU's array: calls that overlap in time on
+ * one GPU race (the library issues them on one stream, so calls from one host thread never do).             */
+#define RT_NOALLOC_MAX_DEPTH 16
+int rt_render_noalloc(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth,
+                      uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
+
 /* rt_render for an interleaved share of the image: the frame is cut into bands of 8 rows (band b =
  * rows [8b, 8b + 8)), and the call renders bands band_first, band_first + band_stride, ... Other rows
  * are not touched. With band_first = rank and band_stride = number of GPUs every GPU gets the same mix

@@ -84,6 +84,7 @@ _PROTOS = {
     "rt_primary_hits": ([C.c_int, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p], C.c_int),
     "rt_hit_rays": ([C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double] + [C.c_void_p] * 5, C.c_int),
     "rt_render": ([C.c_int] * 7 + [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p], C.c_int),
+    "rt_render_noalloc": ([C.c_int] * 7 + [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p], C.c_int),
     "rt_render_bands": ([C.c_int] * 7 + [C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p], C.c_int),
     "rt_render_pixels": ([C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p], C.c_int),
     "rt_trace_rays": ([C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p], C.c_int),

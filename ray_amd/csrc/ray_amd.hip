@@ -842,9 +842,23 @@ __global__ void tonemap_kernel(int W, int H, const float4* __restrict__ accum, i
 // ================================================================================================
 // Host side: context + C ABI
 // ================================================================================================
+// Scratch of rt_render_noalloc (include/ray_amd.h): the 256-byte counter block and the HBM part of the path
+// stack (levels kLdsLevels .. kNoAllocMaxDepth - 1 of every thread of at most kNoAllocMaxGrid blocks), in a
+// file-scope device array instead of hipMalloc'ed buffers. Every GPU the library runs on holds its own copy
+// (40 MiB + 256 B) until the process ends. Host code never uses this NAME as an address: rt_init asks the
+// runtime for the array's device address on the bound device (hipGetSymbolAddress) and keeps it per device.
+constexpr int kNoAllocMaxDepth = RT_NOALLOC_MAX_DEPTH;
+constexpr int kNoAllocMaxGrid = 1024;
+constexpr size_t kScratchCounterBytes = 256;
+constexpr size_t kScratchBytes =
+    kScratchCounterBytes + size_t(kNoAllocMaxDepth - kLdsLevels) * size_t(kNoAllocMaxGrid) * kBlock * sizeof(float4);
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
 namespace {
 
 thread_local std::string g_err;
+constexpr int kMaxDevices = 64;
+void* g_scratch_ptr[kMaxDevices] = {};   // device address of `scratch` on each device rt_init has bound
 
 int fail(const char* fmt, ...) {
     char buf[512];
@@ -1050,6 +1064,12 @@ int rt_init(int device) {
     HIP_OK(hipEventCreate(&g.ev1));
     HIP_OK(hipMalloc(&g.counters, 128));
     HIP_OK(hipMemset(g.counters, 0, 128));
+    if (device < kMaxDevices && !g_scratch_ptr[device]) {   // once per device, with that device current
+        void* sp = nullptr;
+        HIP_OK(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
+        if (!sp) return fail("hipGetSymbolAddress(scratch) returned a null address on device %d", device);
+        g_scratch_ptr[device] = sp;
+    }
     int per_cu = 0;
     HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, false, 0>, kBlock, 0));
     g.render_blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
@@ -1422,8 +1442,10 @@ int rt_trace_rays(int64_t n, const float* d_origin, const float* d_dir, int dept
     return finish_timed(1);
 }
 
+// scratch_dev: nullptr = the library's own buffers (counter block from rt_init, path stack grown by ensure_stack);
+// otherwise the device address of the file-scope `scratch` array (rt_render_noalloc): no allocation on this path.
 static int render_impl(const char* who, int w, int h, int y_begin, int y_count, int band_first, int band_stride, int tiles_y, int spp_begin,
-                       int spp_count, int depth, uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays) {
+                       int spp_count, int depth, uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays, void* scratch_dev = nullptr) {
     if (spp_begin < 0 || spp_count < 0) return fail("%s: bad sample range [%d,+%d)", who, spp_begin, spp_count);
     if (depth < 0 || depth > 128) return fail("%s: depth %d outside 0..128", who, depth);
     if (!d_accum) return fail("%s: null accumulator", who);
@@ -1441,23 +1463,33 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     if (const char* e = getenv("RT_BPC")) resident = g.prop.multiProcessorCount * atoi(e);   // diagnostic: blocks per CU
 #endif
     const int want = (n_tiles + 3) / 4;
-    const int grid = want < resident ? want : resident;
-    if (ensure_stack(depth, grid)) return 1;
+    int grid = want < resident ? want : resident;
+    void* counters = g.counters;
+    float4* stack = nullptr;
+    if (scratch_dev) {   // the stack part of `scratch` holds kNoAllocMaxDepth - kLdsLevels levels of kNoAllocMaxGrid blocks
+        if (grid > kNoAllocMaxGrid) grid = kNoAllocMaxGrid;
+        counters = scratch_dev;
+        stack = reinterpret_cast<float4*>(static_cast<char*>(scratch_dev) + kScratchCounterBytes);
+    } else {
+        if (ensure_stack(depth, grid)) return 1;
+        stack = static_cast<float4*>(g.stack);
+    }
     RenderArgs ra{};
     ra.W = w; ra.H = h; ra.y_begin = y_begin; ra.y_count = y_count; ra.spp_begin = spp_begin; ra.spp_count = spp_count; ra.depth = depth;
     ra.band_first = band_first; ra.band_stride = band_stride; ra.tiles_y = tiles_y;
     ra.seed = seed; ra.flags = flags;
-    ra.accum = reinterpret_cast<float4*>(d_accum); ra.stack = static_cast<float4*>(g.stack);
+    ra.accum = reinterpret_cast<float4*>(d_accum); ra.stack = stack;
     ra.rays_out = reinterpret_cast<unsigned long long*>(d_rays);
-    ra.work_counter = static_cast<unsigned int*>(g.counters);
-    ra.mismatches = reinterpret_cast<unsigned long long*>(static_cast<char*>(g.counters) + 8);
+    ra.work_counter = static_cast<unsigned int*>(counters);
+    ra.mismatches = reinterpret_cast<unsigned long long*>(static_cast<char*>(counters) + 8);
     const bool verify = (flags & RT_RENDER_VERIFY) != 0;
+    // the counter block keeps the last call's contents: the tile counter (and the verify count) must start at zero
 #ifdef RT_STAMPS
-    ra.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(g.counters) + 16);
-    HIP_OK(hipMemsetAsync(g.counters, 0, 128, g.stream));
+    ra.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(counters) + 16);
+    HIP_OK(hipMemsetAsync(counters, 0, 128, g.stream));
 #else
     ra.stamps = nullptr;
-    HIP_OK(hipMemsetAsync(g.counters, 0, verify ? 16 : 4, g.stream));
+    HIP_OK(hipMemsetAsync(counters, 0, verify ? 16 : 4, g.stream));
 #endif
     HIP_OK(hipEventRecord(g.ev0, g.stream));
     const bool many_rects = g.scene.n_rect >= kRectFlagMin;
@@ -1475,6 +1507,23 @@ int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_cou
     if (y_begin < 0 || y_count < 0 || y_begin + y_count > h) return fail("rt_render: rows [%d,+%d) outside 0..%d", y_begin, y_count, h);
     return render_impl("rt_render", w, h, y_begin, y_count, 0, 1, (y_count + kTile - 1) / kTile, spp_begin, spp_count, depth, seed, flags, d_accum,
                        d_rays);
+}
+
+// rt_render without any allocation: scratch (tile counter, HBM part of the path stack) is the file-scope
+// `scratch` array, reached through the per-device address rt_init resolved. include/ray_amd.h has the contract.
+int rt_render_noalloc(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth, uint64_t seed, uint32_t flags,
+                      float* d_accum, uint64_t* d_rays) {
+    if (need_scene_cam()) return 1;
+    if (w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL) return fail("rt_render_noalloc: bad size %dx%d", w, h);
+    if (y_begin < 0 || y_count < 0 || y_begin + y_count > h) return fail("rt_render_noalloc: rows [%d,+%d) outside 0..%d", y_begin, y_count, h);
+    if (depth > kNoAllocMaxDepth)
+        return fail("rt_render_noalloc: depth %d exceeds the limit of %d (the static scratch holds the path stack of %d bounces; use rt_render)",
+                    depth, kNoAllocMaxDepth, kNoAllocMaxDepth);
+    if (flags & RT_RENDER_VERIFY) return fail("rt_render_noalloc: RT_RENDER_VERIFY is an rt_render flag");
+    void* sp = g.device >= 0 && g.device < kMaxDevices ? g_scratch_ptr[g.device] : nullptr;
+    if (!sp) return fail("rt_render_noalloc: no scratch address for device %d (rt_init resolves it)", g.device);
+    return render_impl("rt_render_noalloc", w, h, y_begin, y_count, 0, 1, (y_count + kTile - 1) / kTile, spp_begin, spp_count, depth, seed, flags,
+                       d_accum, d_rays, sp);
 }
 
 int rt_render_bands(int w, int h, int band_first, int band_stride, int spp_begin, int spp_count, int depth, uint64_t seed, uint32_t flags,
