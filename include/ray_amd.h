@@ -12,8 +12,16 @@
  *  - pointers named d_* are DEVICE pointers (HBM) owned by the caller (rt_malloc, hipMalloc or a
  *    torch tensor's data_ptr()); everything else is host memory owned by the caller and may be
  *    freed as soon as the call returns.
- *  - one context per process and per GPU: rt_init(device) binds the context to a HIP device and
- *    creates the stream all kernels run on. Every call is blocking: it returns when its kernel has finished.
+ *  - one context per GPU, any number of GPUs per process: rt_init(device) creates the context of that HIP
+ *    device (scene, camera, stream) on first use and makes it the CURRENT context of the calling host
+ *    thread; rt_set_device(device) switches between initialised contexts. Every other entry point acts on
+ *    the calling thread's current context. Calls are blocking (they return when their kernel has finished)
+ *    unless RT_RENDER_NOWAIT is given. A context must not be used by two threads at the same time.
+ *  - stream ordering: kernels run on the context's stream. By default that is a stream of the library's own
+ *    (hipStreamNonBlocking), which does NOT wait for work the caller queued on other streams: a caller that
+ *    fills or clears d_* buffers asynchronously (torch: tensor.zero_(), a collective) must either
+ *    synchronise its stream before calling, or hand that stream to the library with rt_set_stream(), after
+ *    which the library's kernels are ordered with the caller's work like any other launch on that stream.
  *  - the library never falls back to the CPU: without a usable HIP device every compute entry
  *    point fails with an error.
  */
@@ -81,11 +89,23 @@ typedef struct RtCamera {
 #define RT_RENDER_NORMALS 2u    /* drawOnlyColors mode of calc::ray_color (calc.cpp:105-109)        */
 #define RT_RENDER_VERIFY 4u     /* self-check: every closest-hit scan is repeated as the reference's  */
                                 /* list-order loop and compared (slow; see rt_verify_mismatches)      */
+#define RT_RENDER_NOWAIT 8u     /* rt_render / rt_render_bands / rt_render_noalloc return as soon as  */
+                                /* the kernel is queued; rt_sync() (or the next call on the context)  */
+                                /* waits for it. Lets ONE host thread keep several GPUs busy.          */
 
 /* ---- context ------------------------------------------------------------------------------------ */
 /* Bind this process to HIP device `device` and create the library's stream. Fails (no CPU
  * fallback) when there is no such device.                                                          */
 int rt_init(int device);
+/* Make the (already initialised) context of `device` the calling thread's current one. No counterpart in the
+ * reference (one thread, no device); it is how one C++ caller drives several GPUs (ray_amd/host/render_multi.cpp). */
+int rt_set_device(int device);
+/* Run the current context's kernels on the caller's HIP stream (a hipStream_t, e.g. torch's
+ * torch.cuda.current_stream().cuda_stream; NULL is HIP's default stream, which is torch's default stream)
+ * instead of the library's own; rt_reset_stream() goes back to the library's. See "stream ordering" above.  */
+int rt_set_stream(void* hip_stream);
+int rt_reset_stream(void);
+/* Destroys the calling thread's current context.                                                           */
 void rt_shutdown(void);
 const char* rt_last_error(void);
 /* "name|gcnArch|CUs|clockMHz" of the bound device.                                                 */
@@ -165,7 +185,9 @@ int rt_render_bands(int w, int h, int band_first, int band_stride, int spp_begin
  * pixel. d_pixels holds n pixel indices y * w + x (each in [0, w*h); the caller draws them, e.g. with
  * calc::random_doubleW / H); every listed pixel gets samples [spp_begin, spp_begin + spp_count) exactly as
  * rt_render computes them, its accumulator entry is overwritten (added to with RT_RENDER_ACCUMULATE), and
- * no other pixel is touched. A pixel listed twice is rendered twice with the same result.               */
+ * no other pixel is touched. A pixel listed twice is rendered twice: overwriting, both writes carry the same
+ * values; with RT_RENDER_ACCUMULATE each listing adds its sums and its sample count once (atomic adds of
+ * identical values, so the result does not depend on their order). An index outside [0, w*h) is skipped.   */
 int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_begin, int spp_count, int depth,
                      uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
 

@@ -78,27 +78,34 @@ def golden_scenes():
     r1 = scenes.random_scene(3, 1, aperture=0.1); r1.name = "random3"
     x1 = scenes.box_scene(aperture=0.05); x1.name = "box_a005"
     xn = scenes.box_scene(aperture=0.05, light_on_panel=True); xn.name = "box_nanlight"
-    return dict(builtin_a0=b0, random11_a0=r0, box_a0=x0, builtin=b1, random3=r1, box_a005=x1, box_nanlight=xn)
+    bxy = scenes.builtin_scene(light="xy"); byz = scenes.builtin_scene(light="yz")
+    return dict(builtin_a0=b0, random11_a0=r0, box_a0=x0, builtin=b1, random3=r1, box_a005=x1, box_nanlight=xn,
+                builtin_xylight=bxy, builtin_yzlight=byz)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--missing", action="store_true", help="only write fixtures that do not exist yet")
     args = ap.parse_args()
     if not os.path.exists(HARNESS):
         sys.exit("oracle/_ref/ref_harness missing: run oracle/build_ref.sh first")
     os.makedirs(GOLD, exist_ok=True)
     want = lambda n: args.only is None or args.only == n  # noqa: E731
+    have = lambda name: args.missing and os.path.exists(os.path.join(GOLD, name + ".npz"))  # noqa: E731
     S = golden_scenes()
     with tempfile.TemporaryDirectory() as tmp:
         for unit in ("rng", "vec3", "camera", "shapehits", "materials"):
-            if want(unit):
+            if want(unit) and not have(unit):
                 out = os.path.join(tmp, unit + ".rtfx")
                 run(unit, out)
                 save(unit, read_rtfx(out))
         if want("primary"):
             for sname, W, H in (("builtin_a0", 640, 360), ("builtin_a0", 1920, 1080),
-                                ("random11_a0", 640, 360), ("box_a0", 640, 360)):
+                                ("random11_a0", 640, 360), ("box_a0", 640, 360),
+                                ("random11_a0", 3840, 2160)):        # BASELINE.json configs[2] at its full frame size
+                if have(f"primary_{sname}_{W}x{H}"):
+                    continue
                 sp = scene_file(S[sname], tmp)
                 out = os.path.join(tmp, "p.rtfx")
                 run("primary", sp, W, H, out)
@@ -109,12 +116,15 @@ def main():
                 save(f"primary_{sname}_{W}x{H}", d)
         if want("render"):
             for sname, W, H, spp, depth in (("builtin", 64, 36, 4, 8), ("random3", 48, 27, 2, 10),
-                                            ("box_a005", 48, 27, 2, 6), ("box_nanlight", 32, 18, 2, 6)):
+                                            ("box_a005", 48, 27, 2, 6), ("box_nanlight", 32, 18, 2, 6),
+                                            ("builtin_xylight", 48, 27, 4, 8), ("builtin_yzlight", 48, 27, 4, 8)):
+                if have(f"render_{sname}_{W}x{H}_s{spp}_d{depth}"):
+                    continue
                 sp = scene_file(S[sname], tmp)
                 out = os.path.join(tmp, "r.rtfx")
                 run("render", sp, W, H, spp, depth, 1, 2, 3, out)
                 save(f"render_{sname}_{W}x{H}_s{spp}_d{depth}", read_rtfx(out))
-        if want("mean"):
+        if want("mean") and not have("mean_builtin_160x90"):
             sp = scene_file(S["builtin"], tmp)
             out = os.path.join(tmp, "m.rtfx")
             run("render", sp, 160, 90, 4096, 8, 11, 12, 13, out)

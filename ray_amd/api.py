@@ -14,6 +14,7 @@ from .capi import RtCamera, SceneArrays
 RENDER_ACCUMULATE = 1
 RENDER_NORMALS = 2
 RENDER_VERIFY = 4
+RENDER_NOWAIT = 8
 
 
 class RtError(RuntimeError):
@@ -88,6 +89,17 @@ class Context:
         self._check(self.lib.rt_device_info(buf, 256))
         name, arch, cus, mhz = buf.value.decode().split("|")
         return dict(name=name, arch=arch, cus=int(cus), clock_mhz=int(mhz))
+
+    def set_stream(self, stream=None):
+        """rt_set_stream: run the kernels on the caller's HIP stream (a torch.cuda.Stream, a raw hipStream_t, or None
+        for the library's own), so that they are ordered with the caller's asynchronous work on that stream."""
+        if stream is None:
+            self._check(self.lib.rt_reset_stream())
+        else:
+            self._check(self.lib.rt_set_stream(int(getattr(stream, "cuda_stream", stream)) or None))   # 0 = HIP's default stream
+
+    def sync(self):
+        self._check(self.lib.rt_sync())
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

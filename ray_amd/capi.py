@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -69,6 +70,9 @@ class SceneArrays:
 
 _PROTOS = {
     "rt_init": ([C.c_int], C.c_int),
+    "rt_set_device": ([C.c_int], C.c_int),
+    "rt_set_stream": ([C.c_void_p], C.c_int),
+    "rt_reset_stream": ([], C.c_int),
     "rt_shutdown": ([], None),
     "rt_last_error": ([], C.c_char_p),
     "rt_device_info": ([C.c_char_p, C.c_int], C.c_int),
@@ -101,6 +105,15 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the HIP library is required; there is no CPU fallback)")
+    # PyTorch-ROCm wheels bundle their own HIP / HSA runtime under the same sonames as /opt/rocm's. A process can
+    # initialise the GPU through ONE copy only (the second finds "no HIP GPUs"), so when torch is installed it is
+    # imported first and libray_amd.so then binds to the runtime that is already loaded. Callers that hand torch
+    # tensors or streams to the library need this order anyway.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(path)
     for name, (args, res) in _PROTOS.items():
         fn = getattr(lib, name)

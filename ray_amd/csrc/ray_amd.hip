@@ -658,6 +658,7 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
                 if (PIXELS) {
                     inside = idx < total;
                     const int p = inside ? ra.pixels[idx] : 0;
+                    inside = inside && uint32_t(p) < uint32_t(ra.W) * uint32_t(ra.H);   // an index outside the frame is skipped, never written
                     y = p / ra.W; x = p - y * ra.W;
                 } else {
                     const int tile = idx >> 6, in = idx & 63;
@@ -706,11 +707,18 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
                 path = false;
                 if (++s == spp_end) {
                     float4 a = make_float4(sum.x, sum.y, sum.z, float(ra.spp_count));
-                    if (ra.flags & RT_RENDER_ACCUMULATE) {
-                        float4 o = ra.accum[pix];
-                        a = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + float(ra.spp_count));
+                    if (PIXELS && (ra.flags & RT_RENDER_ACCUMULATE)) {
+                        // a pixel may be listed more than once (the reference draws its pixels at random, rayview.cpp:69-70):
+                        // every listing adds its (identical) sums with one IEEE add each, in whatever order
+                        float* q = reinterpret_cast<float*>(ra.accum + pix);
+                        atomicAdd(q, a.x); atomicAdd(q + 1, a.y); atomicAdd(q + 2, a.z); atomicAdd(q + 3, a.w);
+                    } else {
+                        if (ra.flags & RT_RENDER_ACCUMULATE) {
+                            float4 o = ra.accum[pix];
+                            a = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + float(ra.spp_count));
+                        }
+                        ra.accum[pix] = a;
                     }
-                    ra.accum[pix] = a;
                     have = false;
                 }
             }
@@ -747,16 +755,17 @@ __global__ void render_black_kernel(int W, int y_begin, int y_count, int band_fi
     accum[pix] = a;
 }
 
-__global__ void render_black_pixels_kernel(int n, const int* __restrict__ pixels, int spp_count, uint32_t flags, float4* __restrict__ accum) {
+__global__ void render_black_pixels_kernel(int n, int n_frame, const int* __restrict__ pixels, int spp_count, uint32_t flags, float4* __restrict__ accum) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int pix = pixels[i];
-    float4 a = make_float4(0.0f, 0.0f, 0.0f, float(spp_count));
-    if (flags & RT_RENDER_ACCUMULATE) {
-        float4 o = accum[pix];
-        a = make_float4(o.x + 0.0f, o.y + 0.0f, o.z + 0.0f, o.w + float(spp_count));
+    if (uint32_t(pix) >= uint32_t(n_frame)) return;
+    if (flags & RT_RENDER_ACCUMULATE) {   // duplicates in the list: one add per listing (see render_kernel)
+        float* q = reinterpret_cast<float*>(accum + pix);
+        atomicAdd(q, 0.0f); atomicAdd(q + 1, 0.0f); atomicAdd(q + 2, 0.0f); atomicAdd(q + 3, float(spp_count));
+    } else {
+        accum[pix] = make_float4(0.0f, 0.0f, 0.0f, float(spp_count));
     }
-    accum[pix] = a;
 }
 
 __global__ __launch_bounds__(kBlock) void primary_kernel(DevScene sc, DevCamera cam, int W, int H, uint64_t seed,
@@ -889,9 +898,48 @@ struct Context {
     size_t stack_bytes = 0;
     void* counters = nullptr;   // [0] unsigned int: tile counter of render_kernel; [8] unsigned long long: verify mismatches
     int render_blocks_per_cu = 0;
-} g;
+    hipStream_t own_stream = nullptr;   // created by rt_init; `stream` is this one unless rt_set_stream handed in the caller's
+    bool pending = false;               // a RT_RENDER_NOWAIT launch whose end event has not been waited for yet
+    int pending_launches = 0;
+};
+// One context per HIP device, created by rt_init(device). Every host thread has a CURRENT context (the device of
+// its last rt_init / rt_set_device); all other entry points act on it.
+Context g_ctx[kMaxDevices];
+Context g_none;                              // never ready: what a thread sees before its first rt_init
+thread_local Context* g_cur = &g_none;
+inline Context& G() { return *g_cur; }
 
-int need_ready() { return g.ready ? 0 : fail("rt_init() has not bound a HIP device (no CPU fallback exists)"); }
+int need_ready() {
+    if (!G().ready) return fail("rt_init() has not bound a HIP device (no CPU fallback exists)");
+    hipError_t e = hipSetDevice(G().device);     // the thread may have used another device since
+    if (e != hipSuccess) return fail("hipSetDevice(%d) failed: %s", G().device, hipGetErrorString(e));
+    return 0;
+}
+
+// RT_RENDER_NOWAIT: at most one launch per context is left in flight; rt_sync() or the next call that launches
+// on the context waits for it and takes its time
+int settle() {
+    if (!G().pending) return 0;
+    G().pending = false;
+    HIP_OK(hipStreamSynchronize(G().stream));
+    HIP_OK(hipEventElapsedTime(&G().last_ms, G().ev0, G().ev1));
+    G().last_launches = G().pending_launches;
+    return 0;
+}
+int begin_timed() {
+    if (settle()) return 1;
+    HIP_OK(hipEventRecord(G().ev0, G().stream));
+    return 0;
+}
+int finish_timed(int launches, bool nowait = false) {
+    HIP_OK(hipEventRecord(G().ev1, G().stream));
+    HIP_OK(hipGetLastError());
+    if (nowait) { G().pending = true; G().pending_launches = launches; return 0; }
+    HIP_OK(hipStreamSynchronize(G().stream));
+    HIP_OK(hipEventElapsedTime(&G().last_ms, G().ev0, G().ev1));
+    G().last_launches = launches;
+    return 0;
+}
 
 template <class T, class P>
 int upload(const std::vector<T>& v, P* out) {
@@ -899,16 +947,16 @@ int upload(const std::vector<T>& v, P* out) {
     size_t bytes = (v.empty() ? 1 : v.size()) * sizeof(T);
     void* d = nullptr;
     HIP_OK(hipMalloc(&d, bytes));
-    g.scene_bufs.push_back(d);
+    G().scene_bufs.push_back(d);
     if (!v.empty()) HIP_OK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *out = static_cast<const T*>(d);
     return 0;
 }
 
 void free_scene() {
-    for (void* p : g.scene_bufs) (void)hipFree(p);
-    g.scene_bufs.clear();
-    g.have_scene = false;
+    for (void* p : G().scene_bufs) (void)hipFree(p);
+    G().scene_bufs.clear();
+    G().have_scene = false;
 }
 
 // Partition of one kind's items (bounding spheres: centre xyz + radius w; r2k: the radius^2 the filter
@@ -1040,7 +1088,7 @@ void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k
 }
 
 int grid_for(int n_tiles) {
-    int resident = g.prop.multiProcessorCount * 8;   // 8 blocks of 256 threads per CU = 32 waves/CU
+    int resident = G().prop.multiProcessorCount * 8;   // 8 blocks of 256 threads per CU = 32 waves/CU
     return n_tiles < resident ? (n_tiles > 0 ? n_tiles : 1) : resident;
 }
 
@@ -1054,17 +1102,18 @@ int rt_init(int device) {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail("no HIP device available (%s); this library has no CPU fallback", hipGetErrorString(e));
-    if (device < 0 || device >= n) return fail("device %d out of range (0..%d)", device, n - 1);
-    if (g.ready && g.device == device) return 0;
-    if (g.ready) rt_shutdown();
+    if (device < 0 || device >= n || device >= kMaxDevices) return fail("device %d out of range (0..%d)", device, (n < kMaxDevices ? n : kMaxDevices) - 1);
+    g_cur = &g_ctx[device];
     HIP_OK(hipSetDevice(device));
-    HIP_OK(hipGetDeviceProperties(&g.prop, device));
-    HIP_OK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    HIP_OK(hipEventCreate(&g.ev0));
-    HIP_OK(hipEventCreate(&g.ev1));
-    HIP_OK(hipMalloc(&g.counters, 128));
-    HIP_OK(hipMemset(g.counters, 0, 128));
-    if (device < kMaxDevices && !g_scratch_ptr[device]) {   // once per device, with that device current
+    if (G().ready) return 0;
+    HIP_OK(hipGetDeviceProperties(&G().prop, device));
+    HIP_OK(hipStreamCreateWithFlags(&G().own_stream, hipStreamNonBlocking));
+    G().stream = G().own_stream;
+    HIP_OK(hipEventCreate(&G().ev0));
+    HIP_OK(hipEventCreate(&G().ev1));
+    HIP_OK(hipMalloc(&G().counters, 128));
+    HIP_OK(hipMemset(G().counters, 0, 128));
+    if (!g_scratch_ptr[device]) {   // once per device, with that device current
         void* sp = nullptr;
         HIP_OK(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
         if (!sp) return fail("hipGetSymbolAddress(scratch) returned a null address on device %d", device);
@@ -1072,29 +1121,53 @@ int rt_init(int device) {
     }
     int per_cu = 0;
     HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, false, 0>, kBlock, 0));
-    g.render_blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
-    g.device = device;
-    g.ready = true;
+    G().render_blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    G().device = device;
+    G().ready = true;
+    return 0;
+}
+
+int rt_set_device(int device) {
+    if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready) return fail("rt_set_device: device %d has no context (rt_init it first)", device);
+    g_cur = &g_ctx[device];
+    HIP_OK(hipSetDevice(device));
+    return 0;
+}
+
+int rt_set_stream(void* hip_stream) {
+    if (need_ready()) return 1;
+    if (settle()) return 1;
+    HIP_OK(hipStreamSynchronize(G().stream));    // nothing of ours is left behind on the stream we leave
+    G().stream = static_cast<hipStream_t>(hip_stream);   // NULL is a stream too: HIP's default stream (torch's default)
+    return 0;
+}
+
+int rt_reset_stream(void) {
+    if (need_ready()) return 1;
+    if (settle()) return 1;
+    HIP_OK(hipStreamSynchronize(G().stream));
+    G().stream = G().own_stream;
     return 0;
 }
 
 void rt_shutdown(void) {
-    if (!g.ready) return;
-    (void)hipSetDevice(g.device);
-    (void)hipStreamSynchronize(g.stream);
+    if (!G().ready) return;
+    (void)hipSetDevice(G().device);
+    (void)hipStreamSynchronize(G().stream);
     free_scene();
-    if (g.stack) (void)hipFree(g.stack);
-    g.stack = nullptr; g.stack_bytes = 0;
-    if (g.counters) (void)hipFree(g.counters);
-    g.counters = nullptr;
-    (void)hipEventDestroy(g.ev0); (void)hipEventDestroy(g.ev1);
-    (void)hipStreamDestroy(g.stream);
-    g.ready = false; g.have_cam = false; g.device = -1;
+    if (G().stack) (void)hipFree(G().stack);
+    G().stack = nullptr; G().stack_bytes = 0;
+    if (G().counters) (void)hipFree(G().counters);
+    G().counters = nullptr;
+    (void)hipEventDestroy(G().ev0); (void)hipEventDestroy(G().ev1);
+    (void)hipStreamDestroy(G().own_stream);
+    G().own_stream = nullptr; G().stream = nullptr;
+    G().ready = false; G().have_cam = false; G().have_scene = false; G().pending = false; G().device = -1;
 }
 
 int rt_device_info(char* buf, int buflen) {
     if (need_ready()) return 1;
-    snprintf(buf, buflen, "%s|%s|%d|%d", g.prop.name, g.prop.gcnArchName, g.prop.multiProcessorCount, g.prop.clockRate / 1000);
+    snprintf(buf, buflen, "%s|%s|%d|%d", G().prop.name, G().prop.gcnArchName, G().prop.multiProcessorCount, G().prop.clockRate / 1000);
     return 0;
 }
 
@@ -1102,23 +1175,26 @@ int rt_malloc(void** d_ptr, uint64_t bytes) { if (need_ready()) return 1; HIP_OK
 int rt_free(void* d_ptr) { if (need_ready()) return 1; HIP_OK(hipFree(d_ptr)); return 0; }
 int rt_memcpy_d2h(void* dst, const void* d_src, uint64_t bytes) {
     if (need_ready()) return 1;
-    HIP_OK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, g.stream));
-    HIP_OK(hipStreamSynchronize(g.stream));
+    if (settle()) return 1;
+    HIP_OK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, G().stream));
+    HIP_OK(hipStreamSynchronize(G().stream));
     return 0;
 }
 int rt_memcpy_h2d(void* d_dst, const void* src, uint64_t bytes) {
     if (need_ready()) return 1;
-    HIP_OK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, g.stream));
-    HIP_OK(hipStreamSynchronize(g.stream));
+    if (settle()) return 1;
+    HIP_OK(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, G().stream));
+    HIP_OK(hipStreamSynchronize(G().stream));
     return 0;
 }
 int rt_memset(void* d_ptr, int value, uint64_t bytes) {
     if (need_ready()) return 1;
-    HIP_OK(hipMemsetAsync(d_ptr, value, bytes, g.stream));
-    HIP_OK(hipStreamSynchronize(g.stream));
+    if (settle()) return 1;
+    HIP_OK(hipMemsetAsync(d_ptr, value, bytes, G().stream));
+    HIP_OK(hipStreamSynchronize(G().stream));
     return 0;
 }
-int rt_sync(void) { if (need_ready()) return 1; HIP_OK(hipStreamSynchronize(g.stream)); return 0; }
+int rt_sync(void) { if (need_ready()) return 1; if (settle()) return 1; HIP_OK(hipStreamSynchronize(G().stream)); return 0; }
 
 int rt_upload_scene(const RtScene* s) {
     if (need_ready()) return 1;
@@ -1314,7 +1390,8 @@ int rt_upload_scene(const RtScene* s) {
         }
     }
 
-    HIP_OK(hipStreamSynchronize(g.stream));
+    if (settle()) return 1;
+    HIP_OK(hipStreamSynchronize(G().stream));
     free_scene();
     DevScene ds{};
     ds.n_rect_xy = n_rect_axis[0]; ds.n_rect_xz = n_rect_axis[1]; ds.rect_extent = rect_extent;
@@ -1340,8 +1417,8 @@ int rt_upload_scene(const RtScene* s) {
     ds.light_r = float(s->light_data[3]);
     for (int k = 0; k < 5; ++k) ds.light_rect[k] = s->light_data[k];
     for (int k = 0; k < 3; ++k) ds.bg[k] = s->background[k];
-    g.scene = ds;
-    g.have_scene = true;
+    G().scene = ds;
+    G().have_scene = true;
     return 0;
 }
 
@@ -1371,26 +1448,17 @@ int rt_set_camera(const RtCamera* c) {
     if (need_ready()) return 1;
     if (!c) return fail("rt_set_camera: null camera");
     auto get = [](const float* p) { return v3(p[0], p[1], p[2]); };
-    g.cam.origin = get(c->origin); g.cam.llc = get(c->lower_left_corner); g.cam.horizontal = get(c->horizontal);
-    g.cam.vertical = get(c->vertical); g.cam.u = get(c->u); g.cam.v = get(c->v); g.cam.w = get(c->w);
-    g.cam.lens_radius = c->lens_radius;
-    g.have_cam = true;
+    G().cam.origin = get(c->origin); G().cam.llc = get(c->lower_left_corner); G().cam.horizontal = get(c->horizontal);
+    G().cam.vertical = get(c->vertical); G().cam.u = get(c->u); G().cam.v = get(c->v); G().cam.w = get(c->w);
+    G().cam.lens_radius = c->lens_radius;
+    G().have_cam = true;
     return 0;
 }
 
 static int need_scene_cam() {
     if (need_ready()) return 1;
-    if (!g.have_scene) return fail("no scene uploaded (rt_upload_scene)");
-    if (!g.have_cam) return fail("no camera set (rt_set_camera)");
-    return 0;
-}
-
-static int finish_timed(int launches) {
-    HIP_OK(hipEventRecord(g.ev1, g.stream));
-    HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(g.stream));
-    HIP_OK(hipEventElapsedTime(&g.last_ms, g.ev0, g.ev1));
-    g.last_launches = launches;
+    if (!G().have_scene) return fail("no scene uploaded (rt_upload_scene)");
+    if (!G().have_cam) return fail("no camera set (rt_set_camera)");
     return 0;
 }
 
@@ -1398,47 +1466,48 @@ int rt_primary_hits(int w, int h, uint64_t seed, int32_t* d_prim, double* d_t) {
     if (need_scene_cam()) return 1;
     if (w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL) return fail("rt_primary_hits: bad size %dx%d", w, h);
     int n_tiles = ((w + 15) / 16) * ((h + 15) / 16);
-    HIP_OK(hipEventRecord(g.ev0, g.stream));
-    hipLaunchKernelGGL(primary_kernel, dim3(grid_for(n_tiles)), dim3(kBlock), 0, g.stream, g.scene, g.cam, w, h, seed, d_prim, d_t);
+    if (begin_timed()) return 1;
+    hipLaunchKernelGGL(primary_kernel, dim3(grid_for(n_tiles)), dim3(kBlock), 0, G().stream, G().scene, G().cam, w, h, seed, d_prim, d_t);
     return finish_timed(1);
 }
 
 int rt_hit_rays(int64_t n, const float* d_origin, const float* d_dir, double t_min, double t_max, int32_t* d_prim, double* d_t,
                 float* d_p, float* d_normal, uint8_t* d_front) {
     if (need_ready()) return 1;
-    if (!g.have_scene) return fail("no scene uploaded (rt_upload_scene)");
+    if (!G().have_scene) return fail("no scene uploaded (rt_upload_scene)");
     if (n < 0 || (n > 0 && (!d_origin || !d_dir || !d_prim))) return fail("rt_hit_rays: bad arguments");
-    if (n == 0) { g.last_ms = 0; g.last_launches = 0; return 0; }
+    if (n == 0) { G().last_ms = 0; G().last_launches = 0; return 0; }
     int blocks = int((n + kBlock - 1) / kBlock);
-    HIP_OK(hipEventRecord(g.ev0, g.stream));
-    hipLaunchKernelGGL(hit_rays_kernel, dim3(grid_for(blocks)), dim3(kBlock), 0, g.stream, g.scene, (long long)n, d_origin, d_dir,
+    if (begin_timed()) return 1;
+    hipLaunchKernelGGL(hit_rays_kernel, dim3(grid_for(blocks)), dim3(kBlock), 0, G().stream, G().scene, (long long)n, d_origin, d_dir,
                        t_min, t_max, d_prim, d_t, d_p, d_normal, d_front);
     return finish_timed(1);
 }
 
 static int ensure_stack(int depth, int grid) {
     size_t need = size_t(depth > kLdsLevels ? depth - kLdsLevels : 1) * size_t(grid) * kBlock * sizeof(float4);
-    if (need > g.stack_bytes) {
-        HIP_OK(hipStreamSynchronize(g.stream));
-        if (g.stack) HIP_OK(hipFree(g.stack));
-        g.stack = nullptr; g.stack_bytes = 0;
-        HIP_OK(hipMalloc(&g.stack, need));
-        g.stack_bytes = need;
+    if (need > G().stack_bytes) {
+        HIP_OK(hipStreamSynchronize(G().stream));
+        if (G().stack) HIP_OK(hipFree(G().stack));
+        G().stack = nullptr; G().stack_bytes = 0;
+        HIP_OK(hipMalloc(&G().stack, need));
+        G().stack_bytes = need;
     }
     return 0;
 }
 
 int rt_trace_rays(int64_t n, const float* d_origin, const float* d_dir, int depth, uint64_t seed, uint32_t flags, float* d_rgb) {
     if (need_ready()) return 1;
-    if (!g.have_scene) return fail("no scene uploaded (rt_upload_scene)");
+    if (!G().have_scene) return fail("no scene uploaded (rt_upload_scene)");
     if (n < 0 || (n > 0 && (!d_origin || !d_dir || !d_rgb))) return fail("rt_trace_rays: bad arguments");
     if (depth < 0 || depth > 128) return fail("rt_trace_rays: depth %d outside 0..128", depth);
-    if (n == 0) { g.last_ms = 0; g.last_launches = 0; return 0; }
+    if (n == 0) { G().last_ms = 0; G().last_launches = 0; return 0; }
+    if (settle()) return 1;
     int grid = grid_for(int((n + kBlock - 1) / kBlock));
     if (ensure_stack(depth, grid)) return 1;
-    HIP_OK(hipEventRecord(g.ev0, g.stream));
-    hipLaunchKernelGGL(trace_rays_kernel, dim3(grid), dim3(kBlock), 0, g.stream, g.scene, (long long)n, d_origin, d_dir, depth, seed,
-                       flags, d_rgb, static_cast<float4*>(g.stack));
+    if (begin_timed()) return 1;
+    hipLaunchKernelGGL(trace_rays_kernel, dim3(grid), dim3(kBlock), 0, G().stream, G().scene, (long long)n, d_origin, d_dir, depth, seed,
+                       flags, d_rgb, static_cast<float4*>(G().stack));
     return finish_timed(1);
 }
 
@@ -1449,22 +1518,23 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     if (spp_begin < 0 || spp_count < 0) return fail("%s: bad sample range [%d,+%d)", who, spp_begin, spp_count);
     if (depth < 0 || depth > 128) return fail("%s: depth %d outside 0..128", who, depth);
     if (!d_accum) return fail("%s: null accumulator", who);
-    if (tiles_y == 0) { g.last_ms = 0; g.last_launches = 0; return 0; }
+    if (tiles_y == 0) { G().last_ms = 0; G().last_launches = 0; return 0; }
     if (spp_count == 0 || depth == 0) {   // no ray is traced: every sample is black (calc.cpp:96-97)
         int n = w * tiles_y * kTile;
-        HIP_OK(hipEventRecord(g.ev0, g.stream));
-        hipLaunchKernelGGL(render_black_kernel, dim3((n + 255) / 256), dim3(256), 0, g.stream, w, y_begin, y_count, band_first, band_stride, tiles_y,
+        if (begin_timed()) return 1;
+        hipLaunchKernelGGL(render_black_kernel, dim3((n + 255) / 256), dim3(256), 0, G().stream, w, y_begin, y_count, band_first, band_stride, tiles_y,
                            spp_count, flags, reinterpret_cast<float4*>(d_accum));
-        return finish_timed(1);
+        return finish_timed(1, (flags & RT_RENDER_NOWAIT) != 0);
     }
     const int n_tiles = ((w + kTile - 1) / kTile) * tiles_y;   // one 8x8 tile per wave at a time
-    int resident = g.prop.multiProcessorCount * g.render_blocks_per_cu;
+    int resident = G().prop.multiProcessorCount * G().render_blocks_per_cu;
 #ifdef RT_STAMPS
-    if (const char* e = getenv("RT_BPC")) resident = g.prop.multiProcessorCount * atoi(e);   // diagnostic: blocks per CU
+    if (const char* e = getenv("RT_BPC")) resident = G().prop.multiProcessorCount * atoi(e);   // diagnostic: blocks per CU
 #endif
+    if (settle()) return 1;   // a launch still in flight owns the counters and the stack
     const int want = (n_tiles + 3) / 4;
     int grid = want < resident ? want : resident;
-    void* counters = g.counters;
+    void* counters = G().counters;
     float4* stack = nullptr;
     if (scratch_dev) {   // the stack part of `scratch` holds kNoAllocMaxDepth - kLdsLevels levels of kNoAllocMaxGrid blocks
         if (grid > kNoAllocMaxGrid) grid = kNoAllocMaxGrid;
@@ -1472,7 +1542,7 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
         stack = reinterpret_cast<float4*>(static_cast<char*>(scratch_dev) + kScratchCounterBytes);
     } else {
         if (ensure_stack(depth, grid)) return 1;
-        stack = static_cast<float4*>(g.stack);
+        stack = static_cast<float4*>(G().stack);
     }
     RenderArgs ra{};
     ra.W = w; ra.H = h; ra.y_begin = y_begin; ra.y_count = y_count; ra.spp_begin = spp_begin; ra.spp_count = spp_count; ra.depth = depth;
@@ -1486,18 +1556,18 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     // the counter block keeps the last call's contents: the tile counter (and the verify count) must start at zero
 #ifdef RT_STAMPS
     ra.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(counters) + 16);
-    HIP_OK(hipMemsetAsync(counters, 0, 128, g.stream));
+    HIP_OK(hipMemsetAsync(counters, 0, 128, G().stream));
 #else
     ra.stamps = nullptr;
-    HIP_OK(hipMemsetAsync(counters, 0, verify ? 16 : 4, g.stream));
+    HIP_OK(hipMemsetAsync(counters, 0, verify ? 16 : 4, G().stream));
 #endif
-    HIP_OK(hipEventRecord(g.ev0, g.stream));
-    const bool many_rects = g.scene.n_rect >= kRectFlagMin;
-    if (verify && many_rects) hipLaunchKernelGGL((render_kernel<true, false, 1>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
-    else if (verify) hipLaunchKernelGGL((render_kernel<true, false, 0>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
-    else if (many_rects) hipLaunchKernelGGL((render_kernel<false, false, 1>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
-    else hipLaunchKernelGGL((render_kernel<false, false, 0>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
-    return finish_timed(1);
+    if (begin_timed()) return 1;
+    const bool many_rects = G().scene.n_rect >= kRectFlagMin;
+    if (verify && many_rects) hipLaunchKernelGGL((render_kernel<true, false, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    else if (verify) hipLaunchKernelGGL((render_kernel<true, false, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    else if (many_rects) hipLaunchKernelGGL((render_kernel<false, false, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    else hipLaunchKernelGGL((render_kernel<false, false, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    return finish_timed(1, (flags & RT_RENDER_NOWAIT) != 0);
 }
 
 int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth, uint64_t seed, uint32_t flags,
@@ -1520,8 +1590,8 @@ int rt_render_noalloc(int w, int h, int y_begin, int y_count, int spp_begin, int
         return fail("rt_render_noalloc: depth %d exceeds the limit of %d (the static scratch holds the path stack of %d bounces; use rt_render)",
                     depth, kNoAllocMaxDepth, kNoAllocMaxDepth);
     if (flags & RT_RENDER_VERIFY) return fail("rt_render_noalloc: RT_RENDER_VERIFY is an rt_render flag");
-    void* sp = g.device >= 0 && g.device < kMaxDevices ? g_scratch_ptr[g.device] : nullptr;
-    if (!sp) return fail("rt_render_noalloc: no scratch address for device %d (rt_init resolves it)", g.device);
+    void* sp = G().device >= 0 && G().device < kMaxDevices ? g_scratch_ptr[G().device] : nullptr;
+    if (!sp) return fail("rt_render_noalloc: no scratch address for device %d (rt_init resolves it)", G().device);
     return render_impl("rt_render_noalloc", w, h, y_begin, y_count, 0, 1, (y_count + kTile - 1) / kTile, spp_begin, spp_count, depth, seed, flags,
                        d_accum, d_rays, sp);
 }
@@ -1547,14 +1617,15 @@ int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_b
     if (depth < 0 || depth > 128) return fail("rt_render_pixels: depth %d outside 0..128", depth);
     if (!d_accum || (n > 0 && !d_pixels)) return fail("rt_render_pixels: null pointer");
     if (flags & RT_RENDER_VERIFY) return fail("rt_render_pixels: RT_RENDER_VERIFY is an rt_render flag");
-    if (n == 0) { g.last_ms = 0; g.last_launches = 0; return 0; }
+    if (n == 0) { G().last_ms = 0; G().last_launches = 0; return 0; }
     if (spp_count == 0 || depth == 0) {   // no ray is traced: every sample is black (calc.cpp:96-97)
-        HIP_OK(hipEventRecord(g.ev0, g.stream));
-        hipLaunchKernelGGL(render_black_pixels_kernel, dim3(int((n + 255) / 256)), dim3(256), 0, g.stream, int(n), d_pixels, spp_count, flags,
+        if (begin_timed()) return 1;
+        hipLaunchKernelGGL(render_black_pixels_kernel, dim3(int((n + 255) / 256)), dim3(256), 0, G().stream, int(n), w * h, d_pixels, spp_count, flags,
                            reinterpret_cast<float4*>(d_accum));
         return finish_timed(1);
     }
-    const int resident = g.prop.multiProcessorCount * g.render_blocks_per_cu;
+    if (settle()) return 1;
+    const int resident = G().prop.multiProcessorCount * G().render_blocks_per_cu;
     const int want = int((n + 255) / 256);
     const int grid = want < resident ? want : resident;
     if (ensure_stack(depth, grid)) return 1;
@@ -1562,15 +1633,15 @@ int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_b
     ra.W = w; ra.H = h; ra.y_begin = 0; ra.y_count = h; ra.spp_begin = spp_begin; ra.spp_count = spp_count; ra.depth = depth;
     ra.band_first = 0; ra.band_stride = 1; ra.tiles_y = 0;
     ra.seed = seed; ra.flags = flags;
-    ra.accum = reinterpret_cast<float4*>(d_accum); ra.stack = static_cast<float4*>(g.stack);
+    ra.accum = reinterpret_cast<float4*>(d_accum); ra.stack = static_cast<float4*>(G().stack);
     ra.rays_out = reinterpret_cast<unsigned long long*>(d_rays);
-    ra.work_counter = static_cast<unsigned int*>(g.counters);
+    ra.work_counter = static_cast<unsigned int*>(G().counters);
     ra.mismatches = nullptr; ra.stamps = nullptr;
     ra.pixels = d_pixels; ra.n_pixels = int(n);
-    HIP_OK(hipMemsetAsync(g.counters, 0, 4, g.stream));
-    HIP_OK(hipEventRecord(g.ev0, g.stream));
-    if (g.scene.n_rect >= kRectFlagMin) hipLaunchKernelGGL((render_kernel<false, true, 1>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
-    else hipLaunchKernelGGL((render_kernel<false, true, 0>), dim3(grid), dim3(kBlock), 0, g.stream, g.scene, g.cam, ra);
+    HIP_OK(hipMemsetAsync(G().counters, 0, 4, G().stream));
+    if (begin_timed()) return 1;
+    if (G().scene.n_rect >= kRectFlagMin) hipLaunchKernelGGL((render_kernel<false, true, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    else hipLaunchKernelGGL((render_kernel<false, true, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     return finish_timed(1);
 }
 
@@ -1578,34 +1649,38 @@ int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_b
 // diagnostic builds only (tools/): section cycles and pass counts of the last render
 int rt_debug_stamps(uint64_t out[12]) {
     if (need_ready()) return 1;
-    HIP_OK(hipMemcpyAsync(out, static_cast<char*>(g.counters) + 16, 96, hipMemcpyDeviceToHost, g.stream));
-    HIP_OK(hipStreamSynchronize(g.stream));
+    HIP_OK(hipMemcpyAsync(out, static_cast<char*>(G().counters) + 16, 96, hipMemcpyDeviceToHost, G().stream));
+    HIP_OK(hipStreamSynchronize(G().stream));
     return 0;
 }
 #endif
 
 int rt_verify_mismatches(uint64_t* count) {
     if (need_ready()) return 1;
+    if (settle()) return 1;
     if (!count) return fail("rt_verify_mismatches: null argument");
-    HIP_OK(hipMemcpyAsync(count, static_cast<char*>(g.counters) + 8, 8, hipMemcpyDeviceToHost, g.stream));
-    HIP_OK(hipStreamSynchronize(g.stream));
+    HIP_OK(hipMemcpyAsync(count, static_cast<char*>(G().counters) + 8, 8, hipMemcpyDeviceToHost, G().stream));
+    HIP_OK(hipStreamSynchronize(G().stream));
     return 0;
 }
 
 int rt_tonemap(int w, int h, const float* d_accum, int n_samples, uint32_t* d_rgb32) {
     if (need_ready()) return 1;
-    if (w <= 0 || h <= 0 || !d_accum || !d_rgb32) return fail("rt_tonemap: bad arguments");
+    if (settle()) return 1;
+    if (w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL) return fail("rt_tonemap: bad size %dx%d", w, h);
+    if (!d_accum || !d_rgb32) return fail("rt_tonemap: null pointer");
     int n = w * h;
-    hipLaunchKernelGGL(tonemap_kernel, dim3((n + 255) / 256), dim3(256), 0, g.stream, w, h, reinterpret_cast<const float4*>(d_accum),
+    hipLaunchKernelGGL(tonemap_kernel, dim3((n + 255) / 256), dim3(256), 0, G().stream, w, h, reinterpret_cast<const float4*>(d_accum),
                        n_samples, d_rgb32);
     HIP_OK(hipGetLastError());
-    HIP_OK(hipStreamSynchronize(g.stream));
+    HIP_OK(hipStreamSynchronize(G().stream));
     return 0;
 }
 
 int rt_last_kernel_ms(float* ms, int* launches) {
-    if (ms) *ms = g.last_ms;
-    if (launches) *launches = g.last_launches;
+    if (G().ready && G().pending && settle()) return 1;
+    if (ms) *ms = G().last_ms;
+    if (launches) *launches = G().last_launches;
     return 0;
 }
 

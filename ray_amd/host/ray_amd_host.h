@@ -344,7 +344,9 @@ inline std::vector<uint32_t> renderAll(rt_host::Session& s, int width, int heigh
 class ProgressiveView {
 public:
     ProgressiveView(rt_host::Session& s, int width, int height, int max_depth, uint64_t seed = 0)
-        : s_(s), w_(width), h_(height), depth_(max_depth), seed_(seed), acc_(uint64_t(width) * height * 16), img_(uint64_t(width) * height * 4) {}
+        : s_(s), w_(width), h_(height), depth_(max_depth), seed_(seed), acc_(uint64_t(width) * height * 16), img_(uint64_t(width) * height * 4) {
+        rt_host::check(rt_memset(acc_.p, 0, uint64_t(w_) * h_ * 16));   // pixels never listed by renderPixels() read as "no samples"
+    }
     void reset(const std::vector<std::shared_ptr<shape>>& world, const std::shared_ptr<shape>& lights, const camera& cam,
                const QVector3D& background = img::gradientBgVec) {
         s_.upload(world, lights, background);

@@ -205,8 +205,11 @@ def rayview_camera(aperture: float = 0.1) -> Camera:
                   float(f32(16.0) / f32(9.0)), aperture)
 
 
-def builtin_scene(sphere_y: float = 0.5, aperture: float = 0.1) -> Scene:
-    """normal_scene(), rayview.cpp:233-260, in push_back order."""
+def builtin_scene(sphere_y: float = 0.5, aperture: float = 0.1, light: str = "target") -> Scene:
+    """normal_scene(), rayview.cpp:233-260, in push_back order. `light` selects the shape passed as
+    calc::ray_color's `lights`: "target" = the sphere of rayview.cpp:49; "xy" = the scene's own emitting
+    `rectangle` (exercises rectangle::pdf_value / random, shapes.h:202-219, incl. the k-in-the-y-slot quirk);
+    "yz" = a yz_rect, which has neither (base class shape: value 0, direction (1,0,0), shapes.h:56-62)."""
     mats = [
         Material(MAT_LAMBERTIAN, (0.8, 0.8, 0.0)),      # 0 ground
         Material(MAT_LAMBERTIAN, (0.7, 0.3, 0.3)),      # 1 center
@@ -221,7 +224,9 @@ def builtin_scene(sphere_y: float = 0.5, aperture: float = 0.1) -> Scene:
         Shape("sphere", (-1.0, 0.0, -1.0, 0.6), 2),
         Shape("xy_rect", (3.0, 5.0, 1.0, 3.0, -2.0), 4),
     ]
-    return Scene(mats, world, LIGHT_TARGET, rayview_camera(aperture), name="builtin")
+    lights = {"target": LIGHT_TARGET, "xy": Shape("xy_rect", (3.0, 5.0, 1.0, 3.0, -2.0)),
+              "yz": Shape("yz_rect", (1.0, 3.0, -3.0, -1.0, 4.0))}
+    return Scene(mats, world, lights[light], rayview_camera(aperture), name="builtin" if light == "target" else f"builtin_{light}light")
 
 
 def random_scene(half: int = 11, seed: int = 1, aperture: float = 0.1) -> Scene:

@@ -26,7 +26,8 @@ def test_splits_tile_the_range():
     p = rdist.plan("rows", 64, 36, 16, 1, 4)
     assert p == dict(y_begin=9, y_count=9, band_first=0, band_stride=1, spp_begin=0, spp_count=16, zero_first=True)
     p = rdist.plan("tile", 64, 36, 16, 1, 4)
-    assert p == dict(y_begin=0, y_count=36, band_first=1, band_stride=4, spp_begin=0, spp_count=16, zero_first=True)
+    assert p == dict(y_begin=0, y_count=36, band_first=1, band_stride=4, spp_begin=0, spp_count=16, zero_first=False)
+    assert [rdist.padded_rows(h, w) for h, w in ((36, 4), (2160, 8), (27, 2), (8, 1), (1, 3))] == [64, 2176, 32, 8, 24]
     assert rdist.plan("tile", 64, 36, 16, 0, 1)["zero_first"] is False
     with pytest.raises(ValueError):
         rdist.plan("columns", 1, 1, 1, 0, 1)

@@ -20,7 +20,8 @@ def _outer_side(sc, prim):
 
 # ---- primary-hit ids vs the reference's own output (golden) -------------------------------------------
 @pytest.mark.parametrize("sname,W,H", [("builtin_a0", 640, 360), ("random11_a0", 640, 360), ("box_a0", 640, 360),
-                                       ("builtin_a0", 1920, 1080)])
+                                       ("builtin_a0", 1920, 1080),
+                                       ("random11_a0", 3840, 2160)])   # north_star's frame: 485 spheres at 4K, ids from the reference itself
 def test_primary_ids_match_reference_golden(rt, sname, W, H):
     import hashlib
     g = O.golden(f"primary_{sname}_{W}x{H}")
@@ -126,6 +127,8 @@ def test_shape_fixture_rays_through_gpu(rt):
     ("box", {"aperture": 0.05, "light_on_panel": True}, 32, 18, 4, 6),
     ("tris", {"n": 15}, 64, 36, 4, 6),
     ("mixed", {"half": 2, "n": 9}, 64, 36, 4, 8),
+    ("builtin", {"light": "xy"}, 96, 54, 4, 8),     # lights = the scene's XY `rectangle`: shapes.h:202-219 incl. quirk Q2
+    ("builtin", {"light": "yz"}, 96, 54, 4, 8),     # lights = a yz_rect: base-class pdf_value / random (RT_LIGHT_BASE)
 ])
 def test_radiance_sums_bit_exact_vs_oracle(rt, name, kw, W, H, spp, depth):
     sc = scenes.get_scene(name, **kw)
@@ -136,6 +139,9 @@ def test_radiance_sums_bit_exact_vs_oracle(rt, name, kw, W, H, spp, depth):
     assert O.same_values(acc, oacc)
     if kw.get("light_on_panel"):
         assert np.isnan(oacc).any()
+    if kw.get("light"):
+        assert sc.flatten()["light_kind"] == {"xy": scenes.PRIM_XY_RECT, "yz": scenes.LIGHT_BASE}[kw["light"]]
+        assert np.array_equal(np.isnan(acc), np.isnan(oacc)) and np.isfinite(oacc[..., :3]).mean() > 0.2
 
 
 @pytest.mark.parametrize("name,kw,W,H,spp,depth", [
@@ -611,3 +617,142 @@ def test_rect_flag_pass_sizes_and_edge_rays(rt, n_rect):
         for a, b in zip(got[1:], ref[1:]):
             assert O.same_values(a, b)
     assert (got[0] >= 0).mean() > 0.3
+
+
+def test_triangle_known_answers_on_the_gpu(rt):
+    """tests/tri_kat.py through rt_hit_rays: hand-computed unit-triangle hits, float64 geometry on random triangles
+    (incl. near-in-plane rays from far away), and two triangles against the reference's `rectangle`."""
+    import tri_kat
+
+    def hit_rays(sc, ro, rd, t_min, t_max):
+        rt.upload_scene(sc, set_camera=False)
+        return rt.hit_rays(ro, rd, t_min, t_max)
+    tri_kat.check_unit_triangle(hit_rays)
+    for seed in (5, 6, 7):
+        tri_kat.check_general_triangles(hit_rays, seed=seed)
+    tri_kat.check_triangle_pair_equals_rectangle(hit_rays)
+
+
+def test_render_pixels_duplicates_accumulate_and_stray_indices(rt):
+    """rt_render_pixels with RT_RENDER_ACCUMULATE and a pixel listed k times (RayView::go draws its pixels at random,
+    rayview.cpp:69-70, so repeats are the normal case): the pixel receives k times its sums and k times the sample
+    count, deterministically; indices outside the frame are skipped, not written."""
+    from ray_amd import api
+    sc = scenes.builtin_scene()
+    rt.upload_scene(sc)
+    W, H, spp, depth = 64, 36, 3, 8
+    full, _ = rt.render(W, H, spp, depth, seed=4)
+    base = np.arange(0, W * H, 7, dtype=np.int32)
+    reps = (np.arange(base.size) % 4) + 1                                   # 1..4 listings per pixel
+    px = np.repeat(base, reps)
+    np.random.default_rng(0).shuffle(px)
+    stray = np.array([-1, W * H, W * H + 5, 2 ** 31 - 1, -2 ** 31], np.int32)
+    px = np.concatenate([stray[:2], px, stray[2:]])
+    for trial in range(3):                                                  # same result every time
+        acc = rt.alloc((W * H + 16) * 16).zero()                           # 16 guard entries behind the frame
+        rt.render_pixels(W, H, acc, px, spp, depth, seed=4, flags=api.RENDER_ACCUMULATE)
+        got = acc.to_numpy(np.float32, (W * H + 16, 4))
+        assert (got[W * H:] == 0).all()
+        want = np.zeros((W * H, 4), np.float32)
+        f = full.reshape(-1, 4)
+        for k in range(1, 5):
+            sel = base[reps == k]
+            v = np.zeros((sel.size, 4), np.float32)
+            for _ in range(k):
+                v = v + f[sel]
+            want[sel] = v
+        assert O.same_values(got[:W * H], want)
+        # overwrite mode with the same list: every listed pixel holds the frame's value, strays ignored
+        acc.zero()
+        rt.render_pixels(W, H, acc, px, spp, depth, seed=4)
+        got = acc.to_numpy(np.float32, (W * H + 16, 4))
+        assert O.same_values(got[base], f[base]) and (got[W * H:] == 0).all()
+        acc.zero()
+        rt.render_pixels(W, H, acc, px, 2, 0, seed=4, flags=api.RENDER_ACCUMULATE)     # black path
+        got = acc.to_numpy(np.float32, (W * H + 16, 4))
+        assert (got[base, 3] == 2 * reps).all() and (got[:, :3] == 0).all() and (got[W * H:] == 0).all()
+        acc.free()
+    assert rt.lib.rt_tonemap(70000, 70000, 1, 1, 1) != 0 and b"bad size" in rt.lib.rt_last_error()
+
+
+def test_nowait_launch_and_contexts(rt):
+    """RT_RENDER_NOWAIT returns with the kernel queued; rt_sync (or the next call) waits; results equal the blocking
+    call's. rt_set_device only accepts devices that rt_init has given a context."""
+    from ray_amd import api
+    sc = scenes.get_scene("random", half=4)
+    rt.upload_scene(sc)
+    W, H, spp, depth = 320, 180, 4, 8
+    want, want_rays = rt.render(W, H, spp, depth, seed=3)
+    acc, rays = rt.alloc(W * H * 16).zero(), rt.alloc(8).zero()
+    rt.render_into(W, H, acc, 2, depth, seed=3, rays=rays, flags=api.RENDER_NOWAIT)
+    rt.render_into(W, H, acc, 2, depth, seed=3, rays=rays, spp_begin=2, flags=api.RENDER_NOWAIT | api.RENDER_ACCUMULATE)
+    rt.sync()
+    ms, n = rt.last_kernel_ms()
+    assert ms > 0 and n == 1
+    assert int(rays.to_numpy(np.uint64, (1,))[0]) == want_rays
+    got = acc.to_numpy(np.float32, (H, W, 4))
+    assert (got[..., 3] == 4).all()
+    np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=2e-6, atol=1e-6)
+    acc.zero()
+    rt.render_into(W, H, acc, spp, depth, seed=3, flags=api.RENDER_NOWAIT)
+    assert O.same_values(acc.to_numpy(np.float32, (H, W, 4)), want)        # the copy waits for the launch
+    acc.free(); rays.free()
+    assert rt.lib.rt_set_device(0) == 0
+    assert rt.lib.rt_set_device(63) != 0 and b"no context" in rt.lib.rt_last_error()
+    assert rt.lib.rt_set_device(-1) != 0
+
+
+def test_kernels_are_ordered_with_torch_work_on_a_handed_in_stream(rt):
+    """rt_set_stream (the stream-ordering rule of include/ray_amd.h): with torch's current stream handed to the
+    library, a tensor.zero_() queued before a render and a tensor op queued after it are ordered with the kernel.
+    A large low-spp frame rendered into a torch tensor that is re-filled with garbage and zeroed asynchronously
+    before every pass: bands of other 'ranks' stay zero, the own bands hold the frame."""
+    import torch
+    sc = scenes.get_scene("random", half=11)
+    rt.upload_scene(sc)
+    W, H, depth = 3840, 2160, 8
+    want, _ = rt.render(W, H, 1, depth, seed=0xC0FFEE)
+    dev = torch.device("cuda", 0)
+    acc = torch.empty((H, W, 4), dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    try:
+        for stream in (torch.cuda.current_stream(dev), side):
+            rt.set_stream(stream)
+            with torch.cuda.stream(stream):
+                for first in (0, 1, 0):
+                    acc.fill_(float("nan"))
+                    big = torch.randn(64 * 1024 * 1024, device=dev)       # some queued work in front
+                    big.mul_(2.0)
+                    acc.zero_()
+                    rt.render_into(W, H, acc, 1, depth, seed=0xC0FFEE, band_first=first, band_stride=2)
+                    doubled = acc * 2.0                                    # queued behind the kernel on the same stream
+                    got = acc.cpu().numpy()
+                    mine = np.zeros(H, bool)
+                    for b in range(first, (H + 7) // 8, 2):
+                        mine[8 * b:8 * b + 8] = True
+                    assert (got[~mine] == 0).all()
+                    assert O.same_values(got[mine], want[mine])
+                    assert O.same_values(doubled.cpu().numpy()[mine], 2.0 * want[mine])
+                    del big, doubled
+    finally:
+        rt.set_stream(None)
+    # back on the library's own stream: the documented alternative is to synchronise first
+    acc.fill_(float("nan")); acc.zero_()
+    torch.cuda.synchronize(dev)
+    rt.render_into(W, H, acc, 1, depth, seed=0xC0FFEE, band_first=1, band_stride=2)
+    assert O.same_values(acc.cpu().numpy()[8:16], want[8:16]) and (acc.cpu().numpy()[0:8] == 0).all()
+
+
+def test_two_rank_job_drives_the_hip_library():
+    """tests/dist_worker.py --device under torch.distributed.run with two ranks on this box's one GPU (gloo moves the
+    tensors; RCCL refuses two ranks on one device): spp-split + all-reduce, tile-split + band all-gather, rows-split,
+    all rendered by the HIP library into torch tensors, against the oracle's whole frame."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631", os.path.join(root, "tests", "dist_worker.py"), "--device"],
+                       capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]

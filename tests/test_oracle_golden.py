@@ -245,7 +245,9 @@ def test_primary_hit_ids_bit_exact(sname, W, H):
 
 # ---- calc::ray_color, sequence-exact with the reference's seeded engines (calc.cpp:90-131) ---------
 @pytest.mark.parametrize("sname,W,H,spp,depth", [("builtin", 64, 36, 4, 8), ("random3", 48, 27, 2, 10),
-                                                 ("box_a005", 48, 27, 2, 6), ("box_nanlight", 32, 18, 2, 6)])
+                                                 ("box_a005", 48, 27, 2, 6), ("box_nanlight", 32, 18, 2, 6),
+                                                 ("builtin_xylight", 48, 27, 4, 8),     # lights = an XY `rectangle` (quirk Q2)
+                                                 ("builtin_yzlight", 48, 27, 4, 8)])    # lights = a yz_rect: base-class pdf
 def test_seeded_radiance_sums_bit_exact(sname, W, H, spp, depth):
     g = O.golden(f"render_{sname}_{W}x{H}_s{spp}_d{depth}")
     sc = golden_scenes()[sname]
@@ -284,3 +286,15 @@ def test_render_split_invariance():
     assert O.same_values(bot, full)
     thr, _ = O.render(sc, W, H, 4, 8, rng_mode=1, seed64=7, math_mode=1, n_threads=4)
     assert O.same_values(thr, full)
+
+
+# ---- triangles (not in the reference): analytic known answers, tests/tri_kat.py ------------------------
+def test_triangle_known_answers():
+    """The oracle's Triangle::hit against hand-computed hits on the unit triangle (centre, edges, vertices, back
+    face, parallel and in-plane rays, t-range ends), an independent float64 computation on random triangles, and
+    the reference's `rectangle` tiled by two triangles."""
+    import tri_kat
+    tri_kat.check_unit_triangle(O.hit_rays)
+    for seed in (5, 6):
+        tri_kat.check_general_triangles(O.hit_rays, seed=seed)
+    tri_kat.check_triangle_pair_equals_rectangle(O.hit_rays)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic: host-inclusive times of one frame (scene upload, render, tonemap + image to host, accumulators to host).
     python tools/pcie_probe.py [workload]"""
-import sys, time
-sys.path.insert(0, '/root/repo')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ray_amd import api, scenes
 import bench
 wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else 'c3']
