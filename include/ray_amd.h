@@ -40,13 +40,18 @@ enum {
     RT_PRIM_XY_RECT = 1,  /* shapes.h:161 rectangle     data = {x0, x1, y0, y1, k}   (plane z = k)  */
     RT_PRIM_XZ_RECT = 2,  /* shapes.h:226 xz_rect       data = {x0, x1, z0, z1, k}   (plane y = k)  */
     RT_PRIM_YZ_RECT = 3,  /* shapes.h:292 yz_rect       data = {y0, y1, z0, z1, k}   (plane x = k)  */
-    RT_PRIM_TRIANGLE = 4  /* not in the reference       data = {v0xyz, v1xyz, v2xyz}               */
+    RT_PRIM_TRIANGLE = 4, /* not in the reference       data = {v0xyz, v1xyz, v2xyz}               */
+    /* shapes.h:374 constant_medium, by the shape of its boundary; d = density, data holds -1/d as the
+     * reference stores it (neg_inv_density); the material must be RT_MAT_ISOTROPIC                    */
+    RT_PRIM_MEDIUM_SPHERE = 5, /* boundary = sphere     data = {cx, cy, cz, r, neg_inv_density}    */
+    RT_PRIM_MEDIUM_BOX = 6     /* boundary = box        data = {p0xyz, p1xyz, neg_inv_density}     */
 };
 enum {
     RT_MAT_LAMBERTIAN = 0,    /* hitPosition.h:197  rgb = albedo                                   */
     RT_MAT_METAL = 1,         /* hitPosition.h:222  rgb = albedo, fuzz (already clamped to <= 1)    */
     RT_MAT_DIELECTRIC = 2,    /* hitPosition.h:246  ir                                             */
-    RT_MAT_DIFFUSE_LIGHT = 3  /* hitPosition.h:290  rgb = emitted colour                            */
+    RT_MAT_DIFFUSE_LIGHT = 3, /* hitPosition.h:290  rgb = emitted colour                            */
+    RT_MAT_ISOTROPIC = 4      /* hitPosition.h:316  rgb = albedo; the phase function of a constant_medium */
 };
 enum {
     RT_LIGHT_BASE = -1 /* a shape without pdf_value/random (shapes.h:56-62): value 0, dir (1,0,0)   */
@@ -97,6 +102,8 @@ typedef struct RtCamera {
 /* Bind this process to HIP device `device` and create the library's stream. Fails (no CPU
  * fallback) when there is no such device.                                                          */
 int rt_init(int device);
+/* Number of HIP devices rt_init accepts (0 and an error when there is none).                               */
+int rt_device_count(int* count);
 /* Make the (already initialised) context of `device` the calling thread's current one. No counterpart in the
  * reference (one thread, no device); it is how one C++ caller drives several GPUs (ray_amd/host/render_multi.cpp). */
 int rt_set_device(int device);

@@ -70,6 +70,7 @@ class SceneArrays:
 
 _PROTOS = {
     "rt_init": ([C.c_int], C.c_int),
+    "rt_device_count": ([C.POINTER(C.c_int)], C.c_int),
     "rt_set_device": ([C.c_int], C.c_int),
     "rt_set_stream": ([C.c_void_p], C.c_int),
     "rt_reset_stream": ([], C.c_int),

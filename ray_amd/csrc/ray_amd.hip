@@ -1127,6 +1127,15 @@ int rt_init(int device) {
     return 0;
 }
 
+int rt_device_count(int* count) {
+    if (!count) return fail("rt_device_count: null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail("hipGetDeviceCount failed: %s", hipGetErrorString(e)); }
+    *count = n < kMaxDevices ? n : kMaxDevices;
+    return 0;
+}
+
 int rt_set_device(int device) {
     if (device < 0 || device >= kMaxDevices || !g_ctx[device].ready) return fail("rt_set_device: device %d has no context (rt_init it first)", device);
     g_cur = &g_ctx[device];

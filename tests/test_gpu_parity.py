@@ -756,3 +756,88 @@ def test_two_rank_job_drives_the_hip_library():
                         "--master-port", "29631", os.path.join(root, "tests", "dist_worker.py"), "--device"],
                        capture_output=True, text=True, env=env, timeout=280)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_reference_signature_caller_renderOneRay(rt, tmp_path):
+    """ray_amd/host/rayview_tick.cpp is RayView::renderOneRay (rayview.cpp:67-87) written against the mirror headers
+    with the reference's own calls -- cam.get_ray(u, v), six-argument calc::ray_color, calc::rgbPerSamples, no session
+    anywhere. Its log is checked sample by sample: (u, v) from the reference's gen01 stream, rays equal to the oracle's
+    camera::get_ray on the same engines, every colour equal to the oracle's ray_color on the stream the call drew from,
+    pixel sums and tonemapped pixels as the reference computes them; the scene is uploaded once per change, not per call."""
+    import ctypes as C
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ray_amd", "host", "rayview_tick")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    ticks, spp, depth, seeds = 40, 3, 10, (5, 6, 7)
+    log = tmp_path / "tick.bin"
+    r = subprocess.run([exe, str(ticks), str(spp), str(depth), *[str(s) for s in seeds], str(log)], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr
+    # uploads: scene, moved sphere, the list alone for hitFromList (no lights), one shape alone for shape::hit
+    m = re.search(r"uploads (\d+), centre ray: list prim (-?\d+) t=(\S+), first sphere alone t=(\S+), world box 1 \((.*?)\)-\((.*?)\) hit 1", r.stdout)
+    assert m, r.stdout
+    assert int(m.group(1)) == 4 and int(m.group(2)) == 0 and float(m.group(3)) == 1.0 and float(m.group(4)) == 1.0   # the tangent hit of SURVEY.md 8c
+    assert [float(x) for x in m.group(5).split()] == [-100.0, np.float32(-200.2), -101.0]      # surrounding_box of the five shapes
+    rec = np.dtype([("uv", "<f4", 2), ("o", "<f4", 3), ("d", "<f4", 3), ("dl2", "<f4"), ("stream", "<u8"), ("c", "<f4", 3)])
+    tick = np.dtype([("xy", "<i4", 2), ("s", rec, spp), ("sum", "<f4", 3), ("px", "<f4", 3)])
+    assert rec.itemsize == 56
+    t = np.fromfile(log, tick)
+    assert t.shape == (2 * ticks,)
+    s = t["s"].reshape(-1)
+    n = s.shape[0]
+    assert np.array_equal(s["stream"], np.arange(n, dtype=np.uint64))        # call k draws from stream k
+    # (u, v): two gen01 draws per sample, (rand + xi) / 800 and / 450 in FP32 (rayview.cpp:80-81)
+    xi = np.empty(2 * n, np.float32)
+    O.lib().orc_refrng_fill(seeds[1], 0, 0.0, 1.0, 0, 2 * n, O.P(xi, C.c_float))
+    xy = np.repeat(t["xy"], spp, axis=0)
+    assert xy[:, 0].min() >= 0 and xy[:, 0].max() <= 800 and xy[:, 1].max() <= 450
+    u = ((xy[:, 0].astype(np.float32) + xi[0::2]) / np.float32(800)).astype(np.float32)
+    v = ((xy[:, 1].astype(np.float32) + xi[1::2]) / np.float32(450)).astype(np.float32)
+    assert O.bits_equal(s["uv"][:, 0].copy(), u) and O.bits_equal(s["uv"][:, 1].copy(), v)
+    # rays: camera::get_ray on the reference's gen11 stream (oracle restatement, pinned by camera.npz)
+    sc = scenes.builtin_scene()
+    cam = O.camera_of(sc)
+    ro, rd, dl2 = np.empty((n, 3), np.float32), np.empty((n, 3), np.float32), np.empty(n, np.float32)
+    O.lib().orc_camera_rays(C.byref(cam), seeds[0], seeds[1], seeds[2], n, O.P(np.ascontiguousarray(s["uv"]), C.c_float), O.P(ro, C.c_float),
+                            O.P(rd, C.c_float), O.P(dl2, C.c_float))
+    assert O.bits_equal(np.ascontiguousarray(s["o"]), ro) and O.bits_equal(np.ascontiguousarray(s["d"]), rd)
+    assert O.bits_equal(np.ascontiguousarray(s["dl2"]), dl2)
+    # colours: the oracle's ray_color for ray k on counter stream (k, 0, 0); the second half sees the moved sphere
+    moved = scenes.builtin_scene(sphere_y=0.8)
+    for k in range(n):
+        want = O.trace_rays(sc if k < n // 2 else moved, ro[k:k + 1], rd[k:k + 1], depth, seed=k)
+        assert O.same_values(s["c"][k], want[0]), k
+    # pixel sums in sample order, and calc::rgbPerSamples of them
+    acc = np.zeros((2 * ticks, 3), np.float32)
+    for j in range(spp):
+        acc = acc + t["s"]["c"][:, j]
+    assert O.same_values(t["sum"], acc)
+    tone = np.empty((2 * ticks, 3), np.float32)
+    O.lib().orc_tonemap(2 * ticks, O.P(np.ascontiguousarray(t["sum"]), C.c_float), O.P(np.full(2 * ticks, spp, np.int32), C.c_int32), O.P(tone, C.c_float))
+    assert O.same_values(t["px"], tone)
+
+
+@pytest.mark.parametrize("split,shares", [("spp", 3), ("tile", 3), ("tile", 8), ("spp", 1)])
+def test_cpp_multi_device_host(split, shares, tmp_path):
+    """ray_amd/host/render_multi.cpp: one C++ process with one library context per device, shares queued with
+    RT_RENDER_NOWAIT and collected in order -- the multi-GPU split below Python. On this one-GPU box the shares are
+    dealt onto the one device; the merged frame must be the oracle's (bit-exact for disjoint bands, summation-order
+    tolerance for the sample split)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ray_amd", "host", "render_multi")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    W, H, spp, depth, seed = 120, 67, 7, 8, 99
+    out = tmp_path / "acc.bin"
+    r = subprocess.run([exe, str(W), str(H), str(spp), str(depth), str(seed), str(shares), split, str(out)], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr
+    acc = np.fromfile(out, np.float32).reshape(H, W, 4)
+    oacc, orays = O.render(scenes.builtin_scene(), W, H, spp, depth, rng_mode=1, seed64=seed, math_mode=1, n_threads=8)
+    assert f"{orays} rays" in r.stdout and (acc[..., 3] == spp).all()
+    if split == "tile" or shares == 1:
+        assert O.same_values(acc, oacc)
+    else:
+        np.testing.assert_allclose(acc[..., :3], oacc[..., :3], rtol=2e-6, atol=1e-6)
