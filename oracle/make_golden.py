@@ -7,7 +7,7 @@ so the vectors are committed as compressed .npz files (data only: inputs and exp
     ./oracle/build_ref.sh && python oracle/make_golden.py [--only NAME]
 
 Fixtures:
-  rng.npz, vec3.npz, camera.npz, shapehits.npz, materials.npz  -- unit-level known answers
+  rng.npz, vec3.npz, camera.npz, shapehits.npz, materials.npz, medium.npz  -- unit-level known answers
   primary_<scene>_<W>x<H>.npz   -- pixel-centre primary-hit ids (+ box side, t hash, t subsample)
   render_<scene>_<W>x<H>_s<spp>_d<depth>.npz -- seeded sequence-exact radiance sums (RefRng 1,2,3)
   mean_builtin_160x90.npz       -- 4096-spp converged means for statistical comparison
@@ -95,7 +95,7 @@ def main():
     have = lambda name: args.missing and os.path.exists(os.path.join(GOLD, name + ".npz"))  # noqa: E731
     S = golden_scenes()
     with tempfile.TemporaryDirectory() as tmp:
-        for unit in ("rng", "vec3", "camera", "shapehits", "materials"):
+        for unit in ("rng", "vec3", "camera", "shapehits", "materials", "medium"):
             if want(unit) and not have(unit):
                 out = os.path.join(tmp, unit + ".rtfx")
                 run(unit, out)

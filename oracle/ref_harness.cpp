@@ -101,6 +101,14 @@ std::shared_ptr<shape> read_shape(const std::string& kind, std::istream& in, Sce
         QVector3D p0 = rd3(in), p1 = rd3(in);
         return std::make_shared<box>(p0, p1, mat());
     }
+    if (kind == "medium_sphere" || kind == "medium_box") {   // constant_medium(boundary, density, colour): shapes.h:383-388
+        std::shared_ptr<shape> b;
+        if (kind == "medium_sphere") { QVector3D c = rd3(in); float r = (float)rd(in); b = std::make_shared<sphere>(c, r, std::shared_ptr<material>()); }
+        else { QVector3D p0 = rd3(in), p1 = rd3(in); b = std::make_shared<box>(p0, p1, std::shared_ptr<material>()); }
+        double d = rd(in);
+        QVector3D col = rd3(in);
+        return std::make_shared<constant_medium>(b, d, col);
+    }
     fprintf(stderr, "unknown shape kind '%s'\n", kind.c_str());
     exit(2);
 }
@@ -470,6 +478,56 @@ int cmd_materials(const char* outp) {
     return 0;
 }
 
+// constant_medium::hit known answers (shapes.h:390-444): seeded gen01, sphere and box boundaries, rays through,
+// inside, grazing and missing, several densities and t ranges.
+int cmd_medium(const char* outp) {
+    Out o(outp);
+    const size_t N = 6000;
+    std::mt19937 g(9191);
+    std::uniform_real_distribution<float> u(-1.0f, 1.0f);
+    std::uniform_real_distribution<float> u01(0.0f, 1.0f);
+    std::vector<float> ro, rdv, bnd;
+    std::vector<double> dens, tmin, tmax, t;
+    std::vector<int32_t> kind;
+    std::vector<uint8_t> has, ff;
+    std::vector<float> p, n;
+    seed_all(31, 32, 33);
+    for (size_t i = 0; i < N; ++i) {
+        const bool is_box = (i % 2) == 1;
+        QVector3D c(3 * u(g), 3 * u(g), 3 * u(g));
+        float r = 0.2f + 1.5f * u01(g);
+        QVector3D half(0.2f + 1.5f * u01(g), 0.2f + 1.5f * u01(g), 0.2f + 1.5f * u01(g));
+        QVector3D p0 = c - half, p1 = c + half;
+        std::shared_ptr<shape> b;
+        if (is_box) b = std::make_shared<box>(p0, p1, std::shared_ptr<material>());
+        else b = std::make_shared<sphere>(c, r, std::shared_ptr<material>());
+        double d = (i % 7 == 0) ? 100.0 : (i % 7 == 1 ? 0.01 : 0.05 + 3.0 * u01(g));
+        constant_medium m(b, d, QVector3D(1, 1, 1));
+        QVector3D org(5 * u(g), 5 * u(g), 5 * u(g));
+        QVector3D dir;
+        switch (i % 5) {
+        case 0: dir = QVector3D(u(g), u(g), u(g)); break;                                       // random
+        case 1: org = c + QVector3D(u(g), u(g), u(g)) * 0.15f; dir = QVector3D(u(g), u(g), u(g)); break;   // origin inside
+        default: dir = (c + QVector3D(u(g), u(g), u(g)) * 0.5f * (is_box ? 0.2f : r) - org) * (0.2f + 3 * u01(g)); break;   // aimed through
+        }
+        if (is_box && i % 31 == 1) { dir.setX(0); }                                             // parallel to two faces
+        double t0 = (i % 3 == 0) ? 0.001 : (i % 3 == 1 ? -2.0 : (double)(2.0f * u01(g)));
+        double t1 = (i % 4 == 0) ? (double)(1.0f + 8.0f * u01(g)) : calc::infinity;
+        auto h = m.hit(Ray(org, dir), t0, t1);
+        kind.push_back(is_box ? 1 : 0);
+        if (is_box) { push3(bnd, p0); push3(bnd, p1); } else { push3(bnd, c); bnd.push_back(r); bnd.push_back(0); bnd.push_back(0); }
+        dens.push_back(d); push3(ro, org); push3(rdv, dir); tmin.push_back(t0); tmax.push_back(t1);
+        has.push_back(h.has_value());
+        if (h.has_value()) { t.push_back(h->t); push3(p, h->p); push3(n, h->normal); ff.push_back(h->front_face); }
+        else { t.push_back(0); push3(p, QVector3D()); push3(n, QVector3D()); ff.push_back(0); }
+    }
+    o.i4("kind", kind, {N}); o.f4("bound", bnd, {N, 6}); o.f8("density", dens, {N}); o.f4("ray_o", ro, {N, 3}); o.f4("ray_d", rdv, {N, 3});
+    o.f8("t_min", tmin, {N}); o.f8("t_max", tmax, {N}); o.u1("has", has, {N}); o.f8("t", t, {N}); o.f4("p", p, {N, 3});
+    o.f4("n", n, {N, 3}); o.u1("ff", ff, {N});
+    o.i4("seeds", {31, 32, 33}, {3});
+    return 0;
+}
+
 camera make_cam(const Scene& sc) { return camera(sc.from, sc.at, sc.up, sc.focus, sc.vfov, sc.aspect, sc.aperture); }
 
 // Pixel-centre primary rays: u=(x+0.5)/W, v=(y+0.5)/H through camera::get_ray.
@@ -534,7 +592,7 @@ int cmd_render(const char* scene, int W, int H, int spp, int depth, unsigned a, 
 
 int main(int argc, char** argv) {
     if (argc < 3) {
-        fprintf(stderr, "usage: %s rng|vec3|camera|shapehits|materials OUT\n"
+        fprintf(stderr, "usage: %s rng|vec3|camera|shapehits|materials|medium OUT\n"
                         "       %s primary SCENE W H OUT\n"
                         "       %s render SCENE W H SPP DEPTH S S01 S11 [OUT]\n", argv[0], argv[0], argv[0]);
         return 1;
@@ -545,6 +603,7 @@ int main(int argc, char** argv) {
     if (c == "camera") return cmd_camera(argv[2]);
     if (c == "shapehits") return cmd_shapehits(argv[2]);
     if (c == "materials") return cmd_materials(argv[2]);
+    if (c == "medium") return cmd_medium(argv[2]);
     if (c == "primary" && argc == 6) return cmd_primary(argv[2], atoi(argv[3]), atoi(argv[4]), argv[5]);
     if (c == "render" && argc >= 10)
         return cmd_render(argv[2], atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]),

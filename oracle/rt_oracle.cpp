@@ -125,6 +125,45 @@ inline void sincos(double x, double* s, double* c) {
     }
 }
 inline double pow5(double x) { double x2 = x * x; double x4 = x2 * x2; return x4 * x; }
+// fdlibm e_log.c (__ieee754_log) for positive normal finite x, written with IEEE double +,-,*,/ and integer
+// operations on the high word only: log(x) = k*ln2 + log(1+f), 1+f in [sqrt(2)/2, sqrt(2)), log(1+f) from
+// s = f/(2+f) and a degree-14 polynomial in s^2. x = 0 gives -inf (what libm returns for log(0)).
+constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+inline double log_pos(double x) {
+    if (x == 0.0) return -std::numeric_limits<double>::infinity();
+    uint64_t bits; std::memcpy(&bits, &x, 8);
+    int32_t hx = int32_t(bits >> 32);
+    int32_t k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int32_t i0 = (hx + 0x95f64) & 0x100000;
+    bits = (uint64_t(uint32_t(hx | (i0 ^ 0x3ff00000))) << 32) | (bits & 0xffffffffull);   // normalise x or x/2
+    std::memcpy(&x, &bits, 8);
+    k += (i0 >> 20);
+    const double f = x - 1.0;
+    const double dk = double(k);
+    if ((0x000fffff & (2 + hx)) < 3) {                  // |f| < 2^-20
+        if (f == 0.0) return k == 0 ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+        const double R = f * f * (0.5 - 0.33333333333333333 * f);
+        return k == 0 ? f - R : dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    int32_t i = hx - 0x6147a;
+    const double w = z * z;
+    const int32_t j = 0x6b851 - hx;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    i |= j;
+    const double R = t2 + t1;
+    if (i > 0) {
+        const double hfsq = 0.5 * f * f;
+        return k == 0 ? f - (hfsq - s * (hfsq + R)) : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    return k == 0 ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
 }  // namespace pm
 
 // ------------------------------------------------------------------------------------------------
@@ -182,6 +221,7 @@ struct Ctx {
         if (math_mode == 0) { *s = std::sin(x); *c = std::cos(x); } else pm::sincos(x, s, c);
     }
     double pow5(double x) const { return math_mode == 0 ? std::pow(x, 5) : pm::pow5(x); }
+    double log(double x) const { return math_mode == 0 ? std::log(x) : pm::log_pos(x); }
 };
 
 // calc.cpp:43-46: brace-init list, evaluated left to right.
@@ -290,8 +330,9 @@ struct Shape {
     int prim = -1;
     const Material* mat = nullptr;
     virtual ~Shape() {}
-    virtual std::optional<HitRecord> hit(const Ray& r, double t_min, double t_max) const = 0;
-    virtual double pdf_value(const V3&, const V3&) const { return 0.0; }   // shapes.h:56-58
+    // c: the RNG / math context; only constant_medium::hit draws from it (shapes.h:425)
+    virtual std::optional<HitRecord> hit(Ctx& c, const Ray& r, double t_min, double t_max) const = 0;
+    virtual double pdf_value(Ctx&, const V3&, const V3&) const { return 0.0; }   // shapes.h:56-58
     virtual V3 random(Ctx&, const V3&) const { return V3(1, 0, 0); }       // shapes.h:60-62
 };
 
@@ -299,7 +340,7 @@ struct Shape {
 struct Sphere : Shape {
     V3 center; float radius, radiusSquared;
     Sphere(V3 c, float r) : center(c), radius(r), radiusSquared(r * r) {}
-    std::optional<HitRecord> hit(const Ray& ray, double t_min, double t_max) const override {
+    std::optional<HitRecord> hit(Ctx&, const Ray& ray, double t_min, double t_max) const override {
         V3 oc = ray.o - center;
         float a = ray.dl2;
         float b = dot(oc, ray.d);
@@ -323,8 +364,8 @@ struct Sphere : Shape {
         rec.setFaceNormal(ray, outward);
         return rec;
     }
-    double pdf_value(const V3& o, const V3& v) const override {   // shapes.h:117-127
-        auto h = this->hit(Ray(o, v), 0.001, kInf);
+    double pdf_value(Ctx& c, const V3& o, const V3& v) const override {   // shapes.h:117-127
+        auto h = this->hit(c, Ray(o, v), 0.001, kInf);
         if (!h.has_value()) return 0.0;
         double cos_theta_max = std::sqrt(double(1 - radius * radius / (center - o).lengthSquared()));
         double solid_angle = 2 * kPi * (1 - cos_theta_max);
@@ -344,7 +385,7 @@ struct Sphere : Shape {
 struct Rect : Shape {
     int axis; double a0, a1, b0, b1, k;
     Rect(int ax, double A0, double A1, double B0, double B1, double K) : axis(ax), a0(A0), a1(A1), b0(B0), b1(B1), k(K) {}
-    std::optional<HitRecord> hit(const Ray& r, double t_min, double t_max) const override {
+    std::optional<HitRecord> hit(Ctx&, const Ray& r, double t_min, double t_max) const override {
         float ok, dk, oa, da, ob, db;
         if (axis == 0) { ok = r.o.z; dk = r.d.z; oa = r.o.x; da = r.d.x; ob = r.o.y; db = r.d.y; }
         else if (axis == 1) { ok = r.o.y; dk = r.d.y; oa = r.o.x; da = r.d.x; ob = r.o.z; db = r.d.z; }
@@ -365,9 +406,9 @@ struct Rect : Shape {
         return rec;
     }
     // shapes.h:202-214, 268-279; yz_rect has neither (falls to the base class, quirk Q3)
-    double pdf_value(const V3& origin, const V3& v) const override {
+    double pdf_value(Ctx& c, const V3& origin, const V3& v) const override {
         if (axis == 2) return 0.0;
-        auto h = this->hit(Ray(origin, v), 0.001, kInf);
+        auto h = this->hit(c, Ray(origin, v), 0.001, kInf);
         if (!h.has_value()) return 0.0;
         double area = (a1 - a0) * (b1 - b0);
         double distance_squared = h->t * h->t * v.lengthSquared();
@@ -400,7 +441,7 @@ struct Triangle : Shape {
         rt_triangle_bound(fa, fb, fc, ctr, &rb2);
         cb = V3(ctr[0], ctr[1], ctr[2]);
     }
-    std::optional<HitRecord> hit(const Ray& r, double t_min, double t_max) const override {
+    std::optional<HitRecord> hit(Ctx&, const Ray& r, double t_min, double t_max) const override {
         V3 pvec = cross(r.d, e2);
         float det = dot(e1, pvec);
         if (!(det != 0.0f)) return {};
@@ -424,29 +465,76 @@ struct Triangle : Shape {
 };
 
 // hitPosition.cpp:6-22
-inline std::optional<HitRecord> hitFromList(const std::vector<std::unique_ptr<Shape>>& list, const Ray& ray,
+inline std::optional<HitRecord> hitFromList(Ctx& c, const std::vector<std::unique_ptr<Shape>>& list, const Ray& ray,
                                             double t_min, double t_max) {
     double closest_so_far = t_max;
     std::optional<HitRecord> ret;
     for (const auto& object : list) {
-        auto h = object->hit(ray, t_min, closest_so_far);
+        auto h = object->hit(c, ray, t_min, closest_so_far);
         if (h.has_value()) { closest_so_far = h->t; ret = h; }
     }
     return ret;
 }
+
+// shapes.h:339-372: six rects, hit = hitFromList over them (only ever a constant_medium's boundary here: boxes in
+// the world are flattened into their sides by the scene description, with the same result)
+struct Box : Shape {
+    std::vector<std::unique_ptr<Shape>> sides;
+    Box(V3 p0, V3 p1) {
+        sides.push_back(std::make_unique<Rect>(0, p0.x, p1.x, p0.y, p1.y, p1.z));
+        sides.push_back(std::make_unique<Rect>(0, p0.x, p1.x, p0.y, p1.y, p0.z));
+        sides.push_back(std::make_unique<Rect>(1, p0.x, p1.x, p0.z, p1.z, p1.y));
+        sides.push_back(std::make_unique<Rect>(1, p0.x, p1.x, p0.z, p1.z, p0.y));
+        sides.push_back(std::make_unique<Rect>(2, p0.y, p1.y, p0.z, p1.z, p1.x));
+        sides.push_back(std::make_unique<Rect>(2, p0.y, p1.y, p0.z, p1.z, p0.x));
+    }
+    std::optional<HitRecord> hit(Ctx& c, const Ray& r, double t_min, double t_max) const override {
+        return hitFromList(c, sides, r, t_min, t_max);
+    }
+};
+
+// shapes.h:374-455. Every ray whose clamped boundary interval is non-empty draws ONE number from gen01, inside
+// hitFromList's loop; the hit record has normal (1,0,0) and front_face true ("arbitrary", shapes.h:439-440).
+struct ConstantMedium : Shape {
+    std::unique_ptr<Shape> boundary;
+    double neg_inv_density;
+    ConstantMedium(std::unique_ptr<Shape> b, double niv) : boundary(std::move(b)), neg_inv_density(niv) {}
+    std::optional<HitRecord> hit(Ctx& c, const Ray& r, double t_min, double t_max) const override {
+        auto h1 = boundary->hit(c, r, -kInf, kInf);
+        if (!h1.has_value()) return {};
+        auto h2 = boundary->hit(c, r, h1->t + 0.0001, kInf);
+        if (!h2.has_value()) return {};
+        double t1 = h1->t, t2 = h2->t;
+        if (t1 < t_min) t1 = t_min;
+        if (t2 > t_max) t2 = t_max;
+        if (t1 >= t2) return {};
+        if (t1 < 0) t1 = 0;
+        const float ray_length = r.d.length();
+        const double distance_inside_boundary = (t2 - t1) * ray_length;
+        const double hit_distance = neg_inv_density * c.log(double(c.rng.random_double01()));
+        if (hit_distance > distance_inside_boundary) return {};
+        HitRecord rec;
+        rec.t = t1 + hit_distance / ray_length;
+        rec.p = r.at(rec.t);
+        rec.normal = V3(1, 0, 0);
+        rec.front_face = true;
+        rec.mat = mat; rec.prim = prim;
+        return rec;
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // pdfs (hitPosition.h:141-185, hitPosition.cpp:55-72)
 // ------------------------------------------------------------------------------------------------
 struct Pdf {
     virtual ~Pdf() {}
-    virtual double value(const V3& direction) const = 0;
+    virtual double value(Ctx& c, const V3& direction) const = 0;
     virtual V3 generate(Ctx& c) const = 0;
 };
 struct CosinePdf : Pdf {
     Onb uvw;
     explicit CosinePdf(const V3& w) { uvw.build_from_w(w); }
-    double value(const V3& direction) const override {
+    double value(Ctx&, const V3& direction) const override {
         float cosine = dot(direction.normalized(), uvw.axis[2]);
         return (cosine <= 0) ? 0 : cosine / kPi;
     }
@@ -456,13 +544,13 @@ struct HittablePdf : Pdf {
     const Shape* ptr = nullptr; V3 o;
     HittablePdf() {}
     HittablePdf(const Shape* p, const V3& origin) : ptr(p), o(origin) {}
-    double value(const V3& direction) const override { return ptr->pdf_value(o, direction); }
+    double value(Ctx& c, const V3& direction) const override { return ptr->pdf_value(c, o, direction); }
     V3 generate(Ctx& c) const override { return ptr->random(c, o); }
 };
 struct MixturePdf : Pdf {
     const Pdf* p[2];
     MixturePdf(const Pdf* p0, const Pdf* p1) { p[0] = p0; p[1] = p1; }
-    double value(const V3& direction) const override { return 0.5 * p[0]->value(direction) + 0.5 * p[1]->value(direction); }
+    double value(Ctx& c, const V3& direction) const override { return 0.5 * p[0]->value(c, direction) + 0.5 * p[1]->value(c, direction); }
     V3 generate(Ctx& c) const override {
         if (c.rng.random_double01() < 0.5) return p[0]->generate(c);
         return p[1]->generate(c);
@@ -533,6 +621,21 @@ struct Dielectric : Material {
         return true;
     }
 };
+// hitPosition.h:316-337. The reference's scatter leaves scatter_record::is_specular (and pdf_ptr) unset, so
+// calc.cpp:118 reads an indeterminate bool: undefined behaviour. The one reading under which ray_color is defined
+// (a null pdf_ptr cannot be used by the mixture branch) is "specular", which is also what the book this code derives
+// from does for its isotropic phase function; that reading is adopted here and documented as a deviation.
+struct Isotropic : Material {
+    V3 albedo;
+    explicit Isotropic(V3 a) : albedo(a) {}
+    bool scatter(Ctx& c, const Ray&, const HitRecord& rec, ScatterRecord& s) const override {
+        s.specular_ray = Ray(rec.p, random_in_unit_sphere(c));
+        s.attenuation = albedo;
+        s.is_specular = true;
+        s.pdf_ptr.reset();
+        return true;
+    }
+};
 struct DiffuseLight : Material {
     V3 emit;
     explicit DiffuseLight(V3 c) : emit(c) {}
@@ -589,6 +692,10 @@ inline std::unique_ptr<Shape> make_shape(int kind, const double* d) {
     case RT_PRIM_TRIANGLE:
         return std::make_unique<Triangle>(V3(float(d[0]), float(d[1]), float(d[2])), V3(float(d[3]), float(d[4]), float(d[5])),
                                           V3(float(d[6]), float(d[7]), float(d[8])));
+    case RT_PRIM_MEDIUM_SPHERE:
+        return std::make_unique<ConstantMedium>(std::make_unique<Sphere>(V3(float(d[0]), float(d[1]), float(d[2])), float(d[3])), d[4]);
+    case RT_PRIM_MEDIUM_BOX:
+        return std::make_unique<ConstantMedium>(std::make_unique<Box>(V3(float(d[0]), float(d[1]), float(d[2])), V3(float(d[3]), float(d[4]), float(d[5]))), d[6]);
     }
     return nullptr;
 }
@@ -601,6 +708,7 @@ inline bool build_world(const RtScene* sc, World& w) {
         case RT_MAT_METAL: w.mats.push_back(std::make_unique<Metal>(c, sc->mat_fuzz[i])); break;
         case RT_MAT_DIELECTRIC: w.mats.push_back(std::make_unique<Dielectric>(sc->mat_ir[i])); break;
         case RT_MAT_DIFFUSE_LIGHT: w.mats.push_back(std::make_unique<DiffuseLight>(c)); break;
+        case RT_MAT_ISOTROPIC: w.mats.push_back(std::make_unique<Isotropic>(c)); break;
         default: return false;
         }
     }
@@ -612,7 +720,7 @@ inline bool build_world(const RtScene* sc, World& w) {
         w.list.push_back(std::move(s));
     }
     if (sc->light_kind == RT_LIGHT_BASE) w.light = std::make_unique<Rect>(2, 0, 1, 0, 1, 0);   // base-class behaviour
-    else w.light = make_shape(sc->light_kind, sc->light_data);
+    else if (sc->light_kind == RT_PRIM_SPHERE || sc->light_kind == RT_PRIM_XY_RECT || sc->light_kind == RT_PRIM_XZ_RECT) w.light = make_shape(sc->light_kind, sc->light_data);
     if (!w.light) return false;
     w.background = V3(sc->background[0], sc->background[1], sc->background[2]);
     return true;
@@ -624,7 +732,7 @@ inline bool build_world(const RtScene* sc, World& w) {
 inline V3 ray_color(Ctx& c, const Ray& r, const World& w, int depth, bool drawOnlyColors = false) {
     if (depth <= 0.0f) return V3(0, 0, 0);
     ++c.rays;
-    auto hr = hitFromList(w.list, r, kSmallest, kInf);
+    auto hr = hitFromList(c, w.list, r, kSmallest, kInf);
     if (!hr.has_value()) return w.background;
     if (drawOnlyColors) {
         V3 N = (r.at(hr->t) - V3(0.0f, 0.0f, -1.0f)).normalized();
@@ -639,7 +747,7 @@ inline V3 ray_color(Ctx& c, const Ray& r, const World& w, int depth, bool drawOn
     MixturePdf p(&light_pdf, srec.pdf_ptr.get());
     Ray scattered(rec.p, p.generate(c));
     double spdf = rec.mat->scattering_pdf(r, rec, scattered);
-    double pval = p.value(scattered.d);
+    double pval = p.value(c, scattered.d);
     V3 li = ray_color(c, scattered, w, depth - 1);
     return emitted + srec.attenuation * float(spdf) * li / float(pval);
 }
@@ -684,6 +792,27 @@ void orc_sincos(int math_mode, int n, const double* x, double* s, double* cs) {
 void orc_pow5(int math_mode, int n, const double* x, double* y) {
     Ctx c; c.math_mode = math_mode;
     for (int i = 0; i < n; ++i) y[i] = c.pow5(x[i]);
+}
+
+static void put_rec(const std::optional<HitRecord>& h, int i, uint8_t* has, double* t, float* p, float* n, uint8_t* ff, double* uv);
+void orc_log(int math_mode, int n, const double* x, double* y) {
+    Ctx c; c.math_mode = math_mode;
+    for (int i = 0; i < n; ++i) y[i] = c.log(x[i]);
+}
+// medium.npz: the call sequence of ref_harness.cpp cmd_medium, RefRng seeded (31,32,33) once; kind 0 = sphere
+// boundary (bound = cx cy cz r), 1 = box boundary (bound = p0 p1)
+void orc_medium_kat(int n, int math_mode, const int32_t* kind, const float* bound, const double* density, const float* ro, const float* rd,
+                    const double* t_min, const double* t_max, uint8_t* has, double* t, float* p, float* nrm, uint8_t* ff) {
+    Ctx c; c.rng.seed_ref(31, 32, 33); c.math_mode = math_mode;
+    for (int i = 0; i < n; ++i) {
+        const float* b = bound + 6 * i;
+        std::unique_ptr<Shape> bs;
+        if (kind[i] == 0) bs = std::make_unique<Sphere>(V3(b[0], b[1], b[2]), b[3]);
+        else bs = std::make_unique<Box>(V3(b[0], b[1], b[2]), V3(b[3], b[4], b[5]));
+        ConstantMedium m(std::move(bs), -1 / density[i]);
+        Ray r(V3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), V3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]));
+        put_rec(m.hit(c, r, t_min[i], t_max[i]), i, has, t, p, nrm, ff, nullptr);
+    }
 }
 
 void orc_vec3(int n, const float* a, const float* b, float* lsq, float* len, float* nrm, float* dt, float* crs) {
@@ -739,7 +868,8 @@ void orc_shape_hits(int n, const int32_t* kind, const double* prm, const float* 
     for (int i = 0; i < n; ++i) {
         auto s = make_shape(kind[i], prm + size_t(i) * RT_PRIM_STRIDE);
         Ray r(V3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), V3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]));
-        put_rec(s->hit(r, t_min, t_max[i]), i, has, t, p, nrm, ff, uv);
+        Ctx c;
+        put_rec(s->hit(c, r, t_min, t_max[i]), i, has, t, p, nrm, ff, uv);
     }
 }
 
@@ -775,24 +905,24 @@ void orc_materials_kat(const OrcMatKat* k) {
           p3(k->lamb_att, i, s.attenuation);
           V3 sd = g3(k->lamb_sd, i);
           k->lamb_spdf[i] = m.scattering_pdf(rin, rec, Ray(p, sd));
-          k->cos_val[i] = s.pdf_ptr->value(sd);
+          k->cos_val[i] = s.pdf_ptr->value(c, sd);
           p3(k->cos_gen, i, s.pdf_ptr->generate(c));
           HittablePdf hs(&lightS, p);
           V3 gs = hs.generate(c); p3(k->sph_gen, i, gs);
-          k->sph_val[i] = hs.value(i % 2 ? gs : sd);
+          k->sph_val[i] = hs.value(c, i % 2 ? gs : sd);
           V3 pr = g3(k->xz_o, i);
           HittablePdf hr(&lightXZ, pr);
           V3 gr = hr.generate(c); p3(k->xz_gen, i, gr);
-          k->xz_val[i] = hr.value(i % 2 ? gr : sd);
+          k->xz_val[i] = hr.value(c, i % 2 ? gr : sd);
           HittablePdf hxy(&lightXY, p);
           V3 gxy = hxy.generate(c); p3(k->xy_gen, i, gxy);
-          k->xy_val[i] = hxy.value(i % 2 ? V3(4, 2, -2) - p : sd);
+          k->xy_val[i] = hxy.value(c, i % 2 ? V3(4, 2, -2) - p : sd);
           HittablePdf hyz(&lightYZ, p);
           p3(k->yz_gen, i, hyz.generate(c));
-          k->yz_val[i] = hyz.value(sd);
+          k->yz_val[i] = hyz.value(c, sd);
           MixturePdf mp(&hs, s.pdf_ptr.get());
           V3 gm = mp.generate(c); p3(k->mix_gen, i, gm);
-          k->mix_val[i] = mp.value(gm); }
+          k->mix_val[i] = mp.value(c, gm); }
         { V3 ud = d.normalized();
           p3(k->refl, i, reflect(ud, nf));
           double eta = front ? 1.0 / ir : ir;
@@ -824,9 +954,11 @@ void orc_tonemap_rgb32(int w, int h, const float* accum4, int n_samples, uint32_
 int orc_hit_rays(const RtScene* sc, int64_t n, const float* ro, const float* rd, double t_min, double t_max, int32_t* prim,
                  double* t, float* p, float* nrm, uint8_t* ff) {
     World w; if (!build_world(sc, w)) return 1;
+    Ctx c; c.math_mode = 1;
     for (int64_t i = 0; i < n; ++i) {
         Ray r(V3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), V3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]));
-        auto h = hitFromList(w.list, r, t_min, t_max);
+        c.rng.key(0, uint32_t(i), 0);   // a constant_medium in the list draws from the ray's own counter stream (as rt_hit_rays)
+        auto h = hitFromList(c, w.list, r, t_min, t_max);
         prim[i] = h.has_value() ? h->prim : -1;
         if (t) t[i] = h.has_value() ? h->t : 0.0;
         if (p) for (int k = 0; k < 3; ++k) p[3 * i + k] = h.has_value() ? h->p[k] : 0.0f;
@@ -857,12 +989,13 @@ int orc_primary(const RtScene* sc, const RtCamera* cc, int W, int H, int rng_mod
     World w; if (!build_world(sc, w)) return 1;
     Camera cam(*cc);
     Ctx c; c.rng.seed_ref(1, 2, 3);
+    c.math_mode = rng_mode == 1 ? 1 : 0;   // the GPU's configuration: counter RNG + portable log (a constant_medium calls log in the scan)
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) {
             if (rng_mode == 1) c.rng.key(seed, uint32_t(y * W + x), 0);
             float u = (x + 0.5f) / W, v = (y + 0.5f) / H;
             Ray r = cam.get_ray(c, u, v);
-            auto h = hitFromList(w.list, r, kSmallest, kInf);
+            auto h = hitFromList(c, w.list, r, kSmallest, kInf);
             prim[size_t(y) * W + x] = h.has_value() ? h->prim : -1;
             if (t) t[size_t(y) * W + x] = h.has_value() ? h->t : 0.0;
         }

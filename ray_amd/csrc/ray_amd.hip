@@ -55,6 +55,10 @@ struct DevScene {
     float rect_extent;                     // max |coordinate| of the rects
     const float* __restrict__ rect_bbox;   // [12 per pair of batches] the same around every batch of 16 rects (scenes with >= kRectFlagMin rects:
                                            // the rects are then in spatially compact batches, not sorted by axis)
+    int n_med;                             // constant_medium primitives (shapes.h:374-455); any of them: list-order scan only
+    const float* __restrict__ med_bound;   // [n_med][6] sphere boundary: cx, cy, cz, r, -, - ; box boundary: p0 xyz, p1 xyz
+    const double* __restrict__ med_niv;    // [n_med] neg_inv_density
+    const int* __restrict__ med_is_box;    // [n_med]
 };
 
 struct DevCamera {
@@ -234,17 +238,58 @@ struct Hit {
     int prim;   // flattened index, -1 = miss
 };
 
+// box::hit of a constant_medium's boundary (shapes.h:357-360): hitFromList over the six sides in constructor order
+// (shapes.h:347-354) with the reference's own comparisons; only t is needed. idx = 1 > bi = 0: equal t replaces.
+RT_DEV bool box_bound_t(const Ray& r, const float* __restrict__ b, double t_min, double t_max, double* t_out) {
+    const double x0 = double(b[0]), y0 = double(b[1]), z0 = double(b[2]), x1 = double(b[3]), y1 = double(b[4]), z1 = double(b[5]);
+    double closest = t_max, t;
+    bool any = false;
+    if (rect_core(r.o.z, r.d.z, r.o.x, r.d.x, r.o.y, r.d.y, x0, x1, y0, y1, z1, t_min, closest, 1, 0, &t)) { closest = t; any = true; }
+    if (rect_core(r.o.z, r.d.z, r.o.x, r.d.x, r.o.y, r.d.y, x0, x1, y0, y1, z0, t_min, closest, 1, 0, &t)) { closest = t; any = true; }
+    if (rect_core(r.o.y, r.d.y, r.o.x, r.d.x, r.o.z, r.d.z, x0, x1, z0, z1, y1, t_min, closest, 1, 0, &t)) { closest = t; any = true; }
+    if (rect_core(r.o.y, r.d.y, r.o.x, r.d.x, r.o.z, r.d.z, x0, x1, z0, z1, y0, t_min, closest, 1, 0, &t)) { closest = t; any = true; }
+    if (rect_core(r.o.x, r.d.x, r.o.y, r.d.y, r.o.z, r.d.z, y0, y1, z0, z1, x1, t_min, closest, 1, 0, &t)) { closest = t; any = true; }
+    if (rect_core(r.o.x, r.d.x, r.o.y, r.d.y, r.o.z, r.d.z, y0, y1, z0, z1, x0, t_min, closest, 1, 0, &t)) { closest = t; any = true; }
+    *t_out = closest;
+    return any;
+}
+// constant_medium::hit, shapes.h:390-444: entry and exit of the boundary over the whole line, clamped to
+// [t_min, t_max]; ONE draw from the ray's stream (gen01 in the reference) whenever that interval is non-empty.
+__device__ __forceinline__ bool medium_t(const float* __restrict__ b, bool is_box, double neg_inv_density, const Ray& r, Rng& g, double t_min,
+                                         double t_max, double* t_out) {
+    double t1, t2;
+    const float4 s = make_float4(b[0], b[1], b[2], b[3]);
+    if (is_box) {
+        if (!box_bound_t(r, b, -kInf, kInf, &t1)) return false;
+        if (!box_bound_t(r, b, t1 + 0.0001, kInf, &t2)) return false;
+    } else {
+        if (!sphere_t(r, s, -kInf, kInf, 0, -1, &t1)) return false;
+        if (!sphere_t(r, s, t1 + 0.0001, kInf, 0, -1, &t2)) return false;
+    }
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return false;
+    if (t1 < 0) t1 = 0;
+    const float ray_length = length(r.d);
+    const double distance_inside_boundary = (t2 - t1) * double(ray_length);
+    const double hit_distance = neg_inv_density * log_portable(double(g.u01()));
+    if (hit_distance > distance_inside_boundary) return false;
+    *t_out = t1 + hit_distance / double(ray_length);
+    return true;
+}
+
 // hitFromList (hitPosition.cpp:6-22) over the per-kind arrays. For totally ordered t the sequential
 // scan equals "smallest t, ties to the later entry", which is what the grouped scan computes. If any
 // accepted t is NaN the list order matters (a NaN closest_so_far accepts everything after it), so
 // that lane redoes the scan in list order -- rare (a ray component exactly 0 on a plane it lies in).
-__device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const Ray& r, double t_min, double t_max) {
+__device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const Ray& r, double t_min, double t_max, Rng& g) {
     Hit h; h.t = t_max; h.prim = -1;
     for (int i = 0; i < sc.n_prims; ++i) {
         int k = sc.prim_kind[i], j = sc.prim_local[i];
         double t; bool ok;
         if (k == 0) ok = sphere_t(r, sc.sph[j], t_min, h.t, i, h.prim, &t);
         else if (k == 1) ok = rect_t(r, sc.rect_axis[j], sc.rect + 5 * j, t_min, h.t, i, h.prim, &t);
+        else if (k == 3) ok = medium_t(sc.med_bound + 6 * j, sc.med_is_box[j] != 0, sc.med_niv[j], r, g, t_min, h.t, &t);
         else ok = tri_t(r, sc.tri + 16 * j, t_min, h.t, i, h.prim, &t);
         if (ok) { h.t = t; h.prim = i; }
     }
@@ -289,7 +334,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
 // A compile-time choice for the render kernel: the second path's code costs the 485-sphere frame 3 % when it is
 // merely present.
 template <int RECTS = 2>
-__device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, double t_min, double t_max, uint32_t* words RT_STAMP_PARAM) {
+__device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, double t_min, double t_max, Rng& g, uint32_t* words RT_STAMP_PARAM) {
     Hit h; h.t = t_max; h.prim = -1;
     bool ok = sc.fast_ok && ray_in_fast_range(r.o, r.d, r.dl2) && t_min == t_min && t_max == t_max;
     if (ok) {
@@ -335,7 +380,7 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
         if (!saw_nan) scan_triangles(sc, r, t_min, h, words RT_STAMP_ARG);
         ok = !saw_nan;
     }
-    if (!ok) h = closest_hit_listorder(sc, r, t_min, t_max);
+    if (!ok) h = closest_hit_listorder(sc, r, t_min, t_max, g);
     RT_STAMP(4);
     return h;
 }
@@ -356,6 +401,9 @@ __device__ __forceinline__ HitRec hit_record(const DevScene& sc, const Ray& r, c
     } else if (k == 1) {
         int axis = sc.rect_axis[j];
         outward = axis == 0 ? v3(0, 0, 1) : (axis == 1 ? v3(0, 1, 0) : v3(1, 0, 0));
+    } else if (k == 3) {                         // constant_medium: "arbitrary" normal and face, shapes.h:439-440
+        rec.normal = v3(1, 0, 0); rec.front_face = true;
+        return rec;
     } else {
         const float* q = sc.tri + 16 * j;
         outward = v3(q[9], q[10], q[11]);
@@ -483,7 +531,10 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const
     float pdf = kSpecularMark;
     V3 unit_direction = v3(0.0f, 0.0f, 0.0f);
     if (mk == RT_MAT_METAL || mk == RT_MAT_DIELECTRIC) unit_direction = normalized(ray.d);   // hitPosition.h:233,261
-    if (mk == RT_MAT_METAL) {                                               // hitPosition.h:230-239
+    if (mk == RT_MAT_ISOTROPIC) {                                           // hitPosition.h:327-333, read as specular
+        ray = make_ray(rec.p, random_in_unit_sphere(g));
+        w = rgb;
+    } else if (mk == RT_MAT_METAL) {                                        // hitPosition.h:230-239
         V3 reflected = reflect(unit_direction, rec.normal);
         float fuzz = sc.mat_fuzz[m];
         ray = make_ray(rec.p, reflected + fuzz * random_in_unit_sphere(g));
@@ -574,7 +625,7 @@ __device__ __forceinline__ V3 trace_path(const DevScene& sc, Ray ray, Rng& g, in
     const Recip64 rpi = recip64(kPi);
     V3 L = v3(0.0f, 0.0f, 0.0f);
     for (int depth_left = depth; depth_left > 0; --depth_left) {            // depth_left <= 0: black, calc.cpp:96-97
-        Hit h = closest_hit(sc, ray, double(0.001f), kInf, words RT_STAMP_ARG);   // calc.cpp:99
+        Hit h = closest_hit(sc, ray, double(0.001f), kInf, g, words RT_STAMP_ARG);   // calc.cpp:99
         if (shade_bounce(sc, ray, h, g, normals, st, level, rpi, L)) break;
         ++level;
         L = v3(0.0f, 0.0f, 0.0f);
@@ -690,9 +741,10 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
         // ---- one closest-hit scan per lane, then one bounce ------------------------------------------------
         if (path) {
             ++n_rays;
-            Hit h = closest_hit<RECTS>(sc, ray, double(0.001f), kInf, words RT_STAMP_ARG);   // calc.cpp:99
+            Hit h = closest_hit<RECTS>(sc, ray, double(0.001f), kInf, g, words RT_STAMP_ARG);   // calc.cpp:99
             if (VERIFY) {
-                Hit h2 = closest_hit_listorder(sc, ray, double(0.001f), kInf);
+                Rng gv = g;   // scenes with a constant_medium (which draws inside the scan) are rejected for VERIFY by the host
+                Hit h2 = closest_hit_listorder(sc, ray, double(0.001f), kInf, gv);
                 if (h2.prim != h.prim || __double_as_longlong(h2.t) != __double_as_longlong(h.t)) atomicAdd(ra.mismatches, 1ull);
             }
             V3 L;
@@ -785,7 +837,7 @@ __global__ __launch_bounds__(kBlock) void primary_kernel(DevScene sc, DevCamera 
 #ifdef RT_STAMPS
         Stamps stp{};
 #endif
-        Hit h = closest_hit(sc, ray, double(0.001f), kInf, words RT_STAMP_ARG);
+        Hit h = closest_hit(sc, ray, double(0.001f), kInf, g, words RT_STAMP_ARG);
         if (prim_out) prim_out[pix] = h.prim;
         if (t_out) t_out[pix] = h.prim >= 0 ? h.t : 0.0;
     }
@@ -803,7 +855,8 @@ __global__ __launch_bounds__(kBlock) void hit_rays_kernel(DevScene sc, long long
 #ifdef RT_STAMPS
         Stamps stp{};
 #endif
-        Hit h = closest_hit(sc, ray, t_min, t_max, words RT_STAMP_ARG);
+        Rng g; g.key(0ull, uint32_t(i), 0u);   // a constant_medium in the list draws from the ray's own stream
+        Hit h = closest_hit(sc, ray, t_min, t_max, g, words RT_STAMP_ARG);
         prim_out[i] = h.prim;
         if (t_out) t_out[i] = h.prim >= 0 ? h.t : 0.0;
         HitRec rec; rec.p = v3(0, 0, 0); rec.normal = v3(0, 0, 0); rec.front_face = false;
@@ -1214,6 +1267,7 @@ int rt_upload_scene(const RtScene* s) {
     std::vector<float4> sph; std::vector<int> sph_prim;
     std::vector<double> rect; std::vector<int> rect_axis, rect_prim;
     std::vector<float> tri; std::vector<int> tri_prim;
+    std::vector<float> med_bound; std::vector<double> med_niv; std::vector<int> med_is_box;
     std::vector<int> prim_kind(s->n_prims), prim_local(s->n_prims), prim_mat(s->n_prims);
     for (int i = 0; i < s->n_prims; ++i) {
         const double* d = s->prim_data + size_t(i) * RT_PRIM_STRIDE;
@@ -1240,11 +1294,19 @@ int rt_upload_scene(const RtScene* s) {
             const float q[16] = {v0.x, v0.y, v0.z, e1.x, e1.y, e1.z, e2.x, e2.y, e2.z, nn.x, nn.y, nn.z, cb[0], cb[1], cb[2], rb2};
             tri.insert(tri.end(), q, q + 16); tri_prim.push_back(i);
             break; }
+        case RT_PRIM_MEDIUM_SPHERE: case RT_PRIM_MEDIUM_BOX: {
+            if (s->mat_kind[m] != RT_MAT_ISOTROPIC)
+                return fail("rt_upload_scene: primitive %d is a constant_medium but its material %d is not RT_MAT_ISOTROPIC (shapes.h:376-388)", i, m);
+            const bool is_box = s->prim_kind[i] == RT_PRIM_MEDIUM_BOX;
+            prim_kind[i] = 3; prim_local[i] = int(med_niv.size());
+            for (int k = 0; k < 6; ++k) med_bound.push_back(k < (is_box ? 6 : 4) ? float(d[k]) : 0.0f);
+            med_niv.push_back(d[is_box ? 6 : 4]); med_is_box.push_back(is_box ? 1 : 0);
+            break; }
         default: return fail("rt_upload_scene: primitive %d has unknown kind %d", i, s->prim_kind[i]);
         }
     }
     for (int i = 0; i < s->n_mats; ++i)
-        if (s->mat_kind[i] < RT_MAT_LAMBERTIAN || s->mat_kind[i] > RT_MAT_DIFFUSE_LIGHT)
+        if (s->mat_kind[i] < RT_MAT_LAMBERTIAN || s->mat_kind[i] > RT_MAT_ISOTROPIC)
             return fail("rt_upload_scene: material %d has unknown kind %d", i, s->mat_kind[i]);
     if (s->light_kind != RT_LIGHT_BASE && s->light_kind != RT_PRIM_SPHERE && s->light_kind != RT_PRIM_XY_RECT &&
         s->light_kind != RT_PRIM_XZ_RECT)
@@ -1420,7 +1482,11 @@ int rt_upload_scene(const RtScene* s) {
     if (upload(tgb.fx, &tgb.fg.fx) || upload(tgb.fy, &tgb.fg.fy) || upload(tgb.fz, &tgb.fg.fz) || upload(tgb.fk, &tgb.fg.fk) ||
         upload(tgb.bnd, &tgb.fg.bnd) || upload(tgb.wbnd, &tgb.fg.wbnd) || upload(tgb.cbnd, &tgb.fg.cbnd)) return 1;
     tgb.fg.fq = nullptr;
-    ds.sg = sgb.fg; ds.tg = tgb.fg; ds.fast_ok = finite ? 1 : 0;
+    ds.n_med = int(med_niv.size());
+    if (upload(med_bound, &ds.med_bound) || upload(med_niv, &ds.med_niv) || upload(med_is_box, &ds.med_is_box)) return 1;
+    // a constant_medium draws a random number INSIDE hitFromList's loop, for every ray that crosses its boundary within
+    // the closest hit so far: which rays draw depends on list order, so such scenes are scanned in list order only
+    ds.sg = sgb.fg; ds.tg = tgb.fg; ds.fast_ok = finite && ds.n_med == 0 ? 1 : 0;
     ds.light_kind = s->light_kind;
     for (int k = 0; k < 3; ++k) ds.light_c[k] = float(s->light_data[k]);
     ds.light_r = float(s->light_data[3]);
@@ -1562,6 +1628,7 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     ra.work_counter = static_cast<unsigned int*>(counters);
     ra.mismatches = reinterpret_cast<unsigned long long*>(static_cast<char*>(counters) + 8);
     const bool verify = (flags & RT_RENDER_VERIFY) != 0;
+    if (verify && G().scene.n_med > 0) return fail("%s: RT_RENDER_VERIFY has nothing to compare in a scene with a constant_medium (list-order scan only)", who);
     // the counter block keeps the last call's contents: the tile counter (and the verify count) must start at zero
 #ifdef RT_STAMPS
     ra.stamps = reinterpret_cast<unsigned long long*>(static_cast<char*>(counters) + 16);

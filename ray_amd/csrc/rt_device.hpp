@@ -146,6 +146,47 @@ RT_DEV void sincos_portable(double x, double* s, double* c) {
     }
 }
 RT_DEV double pow5_portable(double x) { double x2 = x * x; double x4 = x2 * x2; return x4 * x; }
+// fdlibm e_log.c (__ieee754_log) for x = 0 or positive normal finite x, with IEEE double +,-,*,/ and integer
+// operations on the high word: bit-identical to the oracle's pm::log_pos. Used by constant_medium::hit (shapes.h:425).
+namespace pm {
+constexpr double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                 Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01, Lg3 = 2.857142874366239149e-01,
+                 Lg4 = 2.222219843214978396e-01, Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+}
+RT_DEV double log_portable(double x) {
+    using namespace pm;
+    if (x == 0.0) return -kInf;
+    uint64_t bits = __builtin_bit_cast(uint64_t, x);
+    int32_t hx = int32_t(bits >> 32);
+    int32_t k = (hx >> 20) - 1023;
+    hx &= 0x000fffff;
+    const int32_t i0 = (hx + 0x95f64) & 0x100000;
+    bits = (uint64_t(uint32_t(hx | (i0 ^ 0x3ff00000))) << 32) | (bits & 0xffffffffull);
+    x = __builtin_bit_cast(double, bits);
+    k += (i0 >> 20);
+    const double f = x - 1.0;
+    const double dk = double(k);
+    if ((0x000fffff & (2 + hx)) < 3) {
+        if (f == 0.0) return k == 0 ? 0.0 : dk * ln2_hi + dk * ln2_lo;
+        const double R = f * f * (0.5 - 0.33333333333333333 * f);
+        return k == 0 ? f - R : dk * ln2_hi - ((R - dk * ln2_lo) - f);
+    }
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    int32_t i = hx - 0x6147a;
+    const double w = z * z;
+    const int32_t j = 0x6b851 - hx;
+    const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    i |= j;
+    const double R = t2 + t1;
+    if (i > 0) {
+        const double hfsq = 0.5 * f * f;
+        return k == 0 ? f - (hfsq - s * (hfsq + R)) : dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+    }
+    return k == 0 ? f - s * (f - R) : dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
 
 // ---- counter RNG (DESIGN.md "RNG contract"): PCG-RXS-M-XS-32 stream keyed by (seed, pixel, sample);
 // the reference's three minstd_rand0 engines (calc.h:103-108) all map onto it. --------------------

@@ -21,15 +21,15 @@ import numpy as np
 
 f32 = np.float32
 
-PRIM_SPHERE, PRIM_XY_RECT, PRIM_XZ_RECT, PRIM_YZ_RECT, PRIM_TRIANGLE = 0, 1, 2, 3, 4
-MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT = 0, 1, 2, 3
+PRIM_SPHERE, PRIM_XY_RECT, PRIM_XZ_RECT, PRIM_YZ_RECT, PRIM_TRIANGLE, PRIM_MEDIUM_SPHERE, PRIM_MEDIUM_BOX = 0, 1, 2, 3, 4, 5, 6
+MAT_LAMBERTIAN, MAT_METAL, MAT_DIELECTRIC, MAT_DIFFUSE_LIGHT, MAT_ISOTROPIC = 0, 1, 2, 3, 4
 LIGHT_BASE = -1
 PRIM_STRIDE = 9
 
 _KIND_NAMES = {PRIM_SPHERE: "sphere", PRIM_XY_RECT: "xy_rect", PRIM_XZ_RECT: "xz_rect",
                PRIM_YZ_RECT: "yz_rect", PRIM_TRIANGLE: "triangle"}
 _MAT_NAMES = {MAT_LAMBERTIAN: "lambertian", MAT_METAL: "metal", MAT_DIELECTRIC: "dielectric",
-              MAT_DIFFUSE_LIGHT: "diffuse_light"}
+              MAT_DIFFUSE_LIGHT: "diffuse_light", MAT_ISOTROPIC: "isotropic"}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -76,8 +76,10 @@ class Material:
 
 @dataclasses.dataclass
 class Shape:
-    kind: str                  # sphere | xy_rect | xz_rect | yz_rect | box | triangle
-    data: Tuple[float, ...]    # sphere: cx cy cz r; rect: a0 a1 b0 b1 k; box: p0xyz p1xyz; tri: 9
+    kind: str                  # sphere | xy_rect | xz_rect | yz_rect | box | triangle | medium_sphere | medium_box
+    data: Tuple[float, ...]    # sphere: cx cy cz r; rect: a0 a1 b0 b1 k; box: p0xyz p1xyz; tri: 9;
+                               # medium_sphere: cx cy cz r density; medium_box: p0xyz p1xyz density (constant_medium,
+                               # shapes.h:374; mat = an isotropic material holding the colour)
     mat: int = -1
 
 
@@ -111,7 +113,9 @@ class Scene:
 
         out = ["rtscene 1"]
         for m in self.mats:
-            if m.kind == MAT_DIELECTRIC:
+            if m.kind == MAT_ISOTROPIC:
+                out.append("lambertian " + " ".join(h32(c) for c in m.rgb))   # placeholder slot: a medium carries its own colour
+            elif m.kind == MAT_DIELECTRIC:
                 out.append(f"dielectric {h(m.ir)}")
             elif m.kind == MAT_METAL:
                 out.append("metal " + " ".join(h32(c) for c in m.rgb) + f" {h(m.fuzz)}")
@@ -121,6 +125,9 @@ class Scene:
         def shape_line(s: Shape, with_mat: bool) -> str:
             if s.kind == "triangle":
                 raise ValueError("the reference has no triangle primitive")
+            if s.kind in ("medium_sphere", "medium_box"):   # constant_medium(boundary, density, colour)
+                rgb = self.mats[s.mat].rgb
+                return f"{s.kind} " + " ".join(h32(v) for v in s.data[:-1]) + f" {h(s.data[-1])} " + " ".join(h32(c) for c in rgb)
             if s.kind in ("sphere", "box"):
                 vals = " ".join(h32(v) for v in s.data)
             else:
@@ -157,6 +164,11 @@ class Scene:
                 add(PRIM_YZ_RECT, s.mat, i, -1, s.data)
             elif s.kind == "triangle":
                 add(PRIM_TRIANGLE, s.mat, i, -1, [f32(v) for v in s.data])
+            elif s.kind in ("medium_sphere", "medium_box"):
+                if self.mats[s.mat].kind != MAT_ISOTROPIC:
+                    raise ValueError("a constant_medium's material is its isotropic phase function")
+                geo = [float(f32(v)) for v in s.data[:-1]]
+                add(PRIM_MEDIUM_SPHERE if s.kind == "medium_sphere" else PRIM_MEDIUM_BOX, s.mat, i, -1, geo + [-1.0 / float(s.data[-1])])
             elif s.kind == "box":
                 # reference shapes.h:347-354: constructor order of the six sides
                 p0 = [float(f32(v)) for v in s.data[0:3]]
@@ -336,6 +348,32 @@ def box_scene(aperture: float = 0.0, light_on_panel: bool = False) -> Scene:
     return Scene(mats, w, light, cam, name="box")
 
 
+def smoke_scene(aperture: float = 0.0, density: float = 0.6) -> Scene:
+    """A small room in the manner of box_scene with the reference's remaining shape / material pair in it
+    (SURVEY.md 8f row 3): a box of dark smoke and a ball of white fog (constant_medium over a box and over a sphere,
+    shapes.h:374-455, isotropic phase function hitPosition.h:316-337), a light panel, a metal ball, a glass ball
+    inside the fog's reach. The reference ships no such scene; this one is the build's."""
+    mats = [
+        Material(MAT_LAMBERTIAN, (.65, .05, .05)), Material(MAT_LAMBERTIAN, (.73, .73, .73)), Material(MAT_LAMBERTIAN, (.12, .45, .15)),
+        Material(MAT_DIFFUSE_LIGHT, (7., 7., 7.)), Material(MAT_METAL, (0.8, 0.85, 0.88), fuzz=0.1), Material(MAT_DIELECTRIC, ir=1.5),
+        Material(MAT_ISOTROPIC, (0.05, 0.05, 0.05)), Material(MAT_ISOTROPIC, (1.0, 1.0, 1.0)),
+    ]
+    RED, WHITE, GREEN, LIGHT, METAL, GLASS, SMOKE, FOG = range(8)
+    w = [
+        Shape("yz_rect", (0, 5.55, 0, 5.55, 5.55), GREEN), Shape("yz_rect", (0, 5.55, 0, 5.55, 0), RED),
+        Shape("xz_rect", (1.13, 4.43, 1.27, 4.32, 5.54), LIGHT),
+        Shape("xz_rect", (0, 5.55, 0, 5.55, 0), WHITE), Shape("xz_rect", (0, 5.55, 0, 5.55, 5.55), WHITE),
+        Shape("xy_rect", (0, 5.55, 0, 5.55, 5.55), WHITE),
+        Shape("medium_box", (2.65, 0.0, 2.95, 4.30, 3.30, 4.60, density), SMOKE),
+        Shape("sphere", (1.6, 0.9, 1.9, 0.9), GLASS),
+        Shape("medium_sphere", (1.6, 0.9, 1.9, 1.4, 0.35 * density), FOG),      # fog around (and inside) the glass ball
+        Shape("sphere", (3.9, 0.6, 1.4, 0.6), METAL),
+        Shape("medium_sphere", (2.8, 2.8, 2.8, 30.0, 0.004 * density), FOG),    # thin haze that the camera sits inside
+    ]
+    cam = Camera((2.78, 2.78, -8.0), (2.78, 2.78, 0.0), (0.0, 1.0, 0.0), 10.0, 40.0, 16.0 / 9.0, aperture)
+    return Scene(mats, w, Shape("xz_rect", (1.13, 4.43, 1.27, 4.32, 5.54)), cam, (0.0, 0.0, 0.0), name="smoke")
+
+
 def _height(x: np.ndarray, z: np.ndarray) -> np.ndarray:
     return (0.35 * np.sin(1.3 * x) * np.cos(0.9 * z) + 0.2 * np.sin(2.1 * x + 0.7 * z) + 0.6).astype(np.float32)
 
@@ -383,5 +421,5 @@ def mixed_scene(half: int = 11, n: int = 71, seed: int = 1, aperture: float = 0.
 
 def get_scene(name: str, **kw) -> Scene:
     table = {"builtin": builtin_scene, "random": random_scene, "box": box_scene,
-             "tris": tri_mesh_scene, "mixed": mixed_scene}
+             "tris": tri_mesh_scene, "mixed": mixed_scene, "smoke": smoke_scene}
     return table[name](**kw)

@@ -43,6 +43,8 @@ def lib():
         L.orc_samplers.argtypes = [C.c_uint32] * 3 + [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double] + [f4p] * 4
         L.orc_sincos.argtypes = [C.c_int, C.c_int, f8p, f8p, f8p]
         L.orc_pow5.argtypes = [C.c_int, C.c_int, f8p, f8p]
+        L.orc_log.argtypes = [C.c_int, C.c_int, f8p, f8p]
+        L.orc_medium_kat.argtypes = [C.c_int, C.c_int, i4p, f4p, f8p, f4p, f4p, f8p, f8p, u1p, f8p, f4p, f4p, u1p]
         L.orc_vec3.argtypes = [C.c_int] + [f4p] * 7
         L.orc_camera.argtypes = [f4p, f4p, f4p] + [C.c_double] * 4 + [C.POINTER(RtCamera)]
         L.orc_camera_rays.argtypes = [C.POINTER(RtCamera)] + [C.c_uint32] * 3 + [C.c_int, f4p, f4p, f4p, f4p]

@@ -38,7 +38,7 @@ def test_primary_ids_match_reference_golden(rt, sname, W, H):
 # ---- primary hits with a finite aperture (lens samples from the counter RNG) vs the oracle ------------
 @pytest.mark.parametrize("name,kw,W,H", [("builtin", {}, 320, 180), ("random", {"half": 11}, 320, 180),
                                          ("box", {"aperture": 0.05}, 160, 90), ("tris", {"n": 21}, 160, 90),
-                                         ("mixed", {"half": 3, "n": 11}, 160, 90)])
+                                         ("mixed", {"half": 3, "n": 11}, 160, 90), ("smoke", {"aperture": 0.1}, 160, 90)])
 def test_primary_hits_match_oracle(rt, name, kw, W, H):
     sc = scenes.get_scene(name, **kw)
     rt.upload_scene(sc)
@@ -127,6 +127,8 @@ def test_shape_fixture_rays_through_gpu(rt):
     ("box", {"aperture": 0.05, "light_on_panel": True}, 32, 18, 4, 6),
     ("tris", {"n": 15}, 64, 36, 4, 6),
     ("mixed", {"half": 2, "n": 9}, 64, 36, 4, 8),
+    ("smoke", {}, 96, 54, 4, 10),                   # constant_medium over a box and over spheres + isotropic (shapes.h:374-455)
+    ("smoke", {"aperture": 0.2, "density": 2.5}, 64, 36, 4, 16),
     ("builtin", {"light": "xy"}, 96, 54, 4, 8),     # lights = the scene's XY `rectangle`: shapes.h:202-219 incl. quirk Q2
     ("builtin", {"light": "yz"}, 96, 54, 4, 8),     # lights = a yz_rect: base-class pdf_value / random (RT_LIGHT_BASE)
 ])
@@ -841,3 +843,53 @@ def test_cpp_multi_device_host(split, shares, tmp_path):
         assert O.same_values(acc, oacc)
     else:
         np.testing.assert_allclose(acc[..., :3], oacc[..., :3], rtol=2e-6, atol=1e-6)
+
+
+def test_constant_medium_through_the_c_abi(rt):
+    """constant_medium (shapes.h:374-455) in hitFromList for caller rays: the medium draws from the ray's own counter
+    stream inside the scan, so which rays draw depends on list order; records carry the reference's 'arbitrary' normal
+    (1,0,0) and front_face true. Against the oracle on the smoke scene and on media-only lists (sphere and box
+    boundaries, origins inside, rays parallel to box faces, negative t_min, finite t_max). Plus the upload rules."""
+    from ray_amd import capi
+    rng = np.random.default_rng(17)
+    iso = scenes.Material(scenes.MAT_ISOTROPIC, (0.9, 0.9, 0.9))
+    lam = scenes.Material(scenes.MAT_LAMBERTIAN, (0.5, 0.5, 0.5))
+    only = scenes.Scene([iso, lam], [scenes.Shape("medium_sphere", (0.5, 0.25, -0.5, 1.5, 0.8), 0),
+                                     scenes.Shape("sphere", (0.5, 0.25, -0.5, 0.5), 1),
+                                     scenes.Shape("medium_box", (-2.0, -1.0, -3.0, 0.0, 1.5, 1.0, 2.0), 0),
+                                     scenes.Shape("medium_box", (-1.0, -0.5, -1.0, 3.0, 0.5, 0.0, 0.05), 0)], None, scenes.rayview_camera())
+    for sc in (scenes.smoke_scene(), only):
+        rt.upload_scene(sc, set_camera=False)
+        n = 30000
+        lo, hi = (-1.0, 7.0) if sc.name == "smoke" else (-4.0, 4.0)
+        ro = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+        rd = (rng.uniform(lo, hi, (n, 3)) - ro).astype(np.float32) * rng.choice([0.1, 1.0, 6.0], (n, 1)).astype(np.float32)
+        rd[::17, 0] = 0.0                      # parallel to two faces of every box
+        rd[5::29] = 0.0                        # zero direction
+        seen = 0
+        for t_min, t_max in [(0.001, np.inf), (-3.0, np.inf), (0.2, 2.5)]:
+            got = rt.hit_rays(ro, rd, t_min, t_max)
+            ref = O.hit_rays(sc, ro, rd, t_min, t_max)
+            assert np.array_equal(got[0], ref[0])
+            assert O.bits_equal(got[1], ref[1])
+            for a, b in zip(got[2:], ref[2:]):
+                assert O.same_values(a, b)
+            kinds = sc.flatten()["prim_kind"]
+            med = (got[0] >= 0) & np.isin(kinds[np.maximum(got[0], 0)], (scenes.PRIM_MEDIUM_SPHERE, scenes.PRIM_MEDIUM_BOX))
+            assert (got[3][med] == (1, 0, 0)).all() and (got[4][med] == 1).all()
+            seen += int(med.sum())
+        assert seen > n // 4
+    # RT_RENDER_VERIFY has nothing to compare on such a scene; a medium must carry an isotropic material
+    acc, rays = rt.alloc(16 * 16 * 16), rt.alloc(8)
+    assert rt.lib.rt_render(16, 16, 0, 16, 0, 1, 4, 0, 4, acc.ptr, rays.ptr) != 0 and b"constant_medium" in rt.lib.rt_last_error()
+    bad = scenes.Scene([lam, iso], [scenes.Shape("medium_sphere", (0, 0, 0, 1, 1.0), 1)], None, scenes.rayview_camera())
+    flat = bad.flatten(); flat["prim_mat"][:] = 0
+    assert rt.lib.rt_upload_scene(capi.SceneArrays(flat).ref()) != 0 and b"RT_MAT_ISOTROPIC" in rt.lib.rt_last_error()
+    acc.free(); rays.free()
+    # an isotropic SURFACE (a sphere whose material is isotropic) scatters uniformly and is read as specular
+    surf = scenes.Scene([iso, lam], [scenes.Shape("sphere", (0.0, 0.0, -1.0, 0.5), 0), scenes.Shape("sphere", (0.0, -100.5, -1.0, 100.0), 1)],
+                        scenes.LIGHT_TARGET, scenes.rayview_camera())
+    rt.upload_scene(surf)
+    a, r = rt.render(64, 36, 4, 8, seed=3)
+    oa, orr = O.render(surf, 64, 36, 4, 8, rng_mode=1, seed64=3, math_mode=1)
+    assert r == orr and O.same_values(a, oa)

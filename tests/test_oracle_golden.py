@@ -298,3 +298,42 @@ def test_triangle_known_answers():
     for seed in (5, 6):
         tri_kat.check_general_triangles(O.hit_rays, seed=seed)
     tri_kat.check_triangle_pair_equals_rectangle(O.hit_rays)
+
+
+# ---- constant_medium::hit (shapes.h:374-455) ---------------------------------------------------------------
+def _medium_kat(math_mode):
+    g = O.golden("medium")
+    n = g["kind"].shape[0]
+    has, t, p = np.empty(n, np.uint8), np.empty(n), np.empty((n, 3), np.float32)
+    nrm, ff = np.empty((n, 3), np.float32), np.empty(n, np.uint8)
+    O.lib().orc_medium_kat(n, math_mode, O.P(g["kind"], C.c_int32), O.P(g["bound"], C.c_float), O.P(g["density"], C.c_double),
+                           O.P(g["ray_o"], C.c_float), O.P(g["ray_d"], C.c_float), O.P(g["t_min"], C.c_double), O.P(g["t_max"], C.c_double),
+                           O.P(has, C.c_uint8), O.P(t, C.c_double), O.P(p, C.c_float), O.P(nrm, C.c_float), O.P(ff, C.c_uint8))
+    return g, has, t, p, nrm, ff
+
+
+def test_constant_medium_hits_bit_exact():
+    """6000 seeded cases from the reference (sphere and box boundaries, rays through / inside / missing / parallel to
+    faces, densities 0.01..100, t ranges incl. negative t_min and finite t_max): has, t bits, p, normal, front_face."""
+    g, has, t, p, nrm, ff = _medium_kat(0)
+    assert np.array_equal(has, g["has"]) and 0.3 < has.mean() < 0.6
+    assert O.bits_equal(t, g["t"]) and O.same_values(p, g["p"])
+    assert np.array_equal(nrm, g["n"]) and np.array_equal(ff, g["ff"])
+    assert (nrm[has == 1] == (1, 0, 0)).all() and (ff[has == 1] == 1).all()          # "arbitrary", shapes.h:439-440
+
+
+def test_portable_log_within_one_ulp_of_libm():
+    """math_mode 1 replaces libm's log (not reproducible on the GPU) by fdlibm's algorithm in IEEE operations: never
+    more than 1 ulp from libm on every value a float draw can take, and the medium fixture moves by at most that."""
+    x = np.concatenate([np.arange(1, 2 ** 24, 37, dtype=np.float64) * 2.0 ** -24, np.random.default_rng(0).random(100000)])
+    y0, y1 = np.empty_like(x), np.empty_like(x)
+    O.lib().orc_log(0, x.size, O.P(x, C.c_double), O.P(y0, C.c_double))
+    O.lib().orc_log(1, x.size, O.P(x, C.c_double), O.P(y1, C.c_double))
+    assert _ulps(y0, y1).max() <= 1
+    z = np.zeros(1); out = np.empty(1)
+    O.lib().orc_log(1, 1, O.P(z, C.c_double), O.P(out, C.c_double))
+    assert out[0] == -np.inf
+    g, has, t, p, nrm, ff = _medium_kat(1)
+    assert np.array_equal(has, g["has"])
+    both = has == 1
+    assert _ulps(t[both], g["t"][both]).max() <= 4 and (t != g["t"]).mean() < 0.02
