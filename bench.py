@@ -105,6 +105,56 @@ def cpu_baseline(scene, wl, budget_s=12.0):
     return out
 
 
+def executed_work(pmc, k_ms):
+    """Executed (not algorithmic) VALU work of one render_kernel launch from a committed rocprofv3 PMC summary
+    (profiles/r2_pmc.json, written by tools/prof.sh for exactly this configuration). How gfx950 counts, settled with
+    tools/valu_bench under --pmc (profiles/r2_valu_bench_pmc.txt): SQ_INSTS_VALU_{FMA,MUL,ADD}_F32 count one per
+    wave-instruction whether packed or not, so executed FP32 flops are only bounded: [every instruction unpacked,
+    every instruction packed]; SQ_ACTIVE_INST_VALU counts issue slots of 4 cycles (FP64 fma/mul/add and conversions
+    take one slot like FP32, v_rcp/rsq_f64 four, v_rcp/sqrt_f32 two); SQ_THREAD_CYCLES_VALU adds 64 per slot with all
+    lanes on; SQ_INSTS_VALU_FLOPS_FP64 counts 2 per FP64 fma and 1 per mul/add/rcp/rsq."""
+    c = pmc["counters_per_launch"]
+    t = pmc["avg_ns"] * 1e-9
+    fma, mul, add = c["SQ_INSTS_VALU_FMA_F32"], c["SQ_INSTS_VALU_MUL_F32"], c["SQ_INSTS_VALU_ADD_F32"]
+    lo = (2 * fma + mul + add) * 64 / t / 1e12
+    lane_util = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0)
+    return {
+        "executed_tflops_range": [round(lo, 2), round(2 * lo, 2)],
+        "executed_frac_range": [round(lo / FP32_VALU_PEAK_TFLOPS, 4), round(2 * lo / FP32_VALU_PEAK_TFLOPS, 4)],
+        "lane_util": round(lane_util, 4),
+        # issue slots used / available: 4 cycles per slot, 256 CUs x 4 SIMDs at 2.4 GHz for the profiled launch's duration
+        "valu_issue_utilisation": round(c["SQ_ACTIVE_INST_VALU"] * 4 / (t * 2.4e9 * 1024), 4),
+        "fp64_issue_share_max": round(c["SQ_INSTS_VALU_FLOPS_FP64"] / c["SQ_ACTIVE_INST_VALU"], 4),
+        "valu_insts_per_ray": None,
+        "profile_kernel_ms": round(pmc["avg_ns"] * 1e-6, 3),
+        "profile_vs_live_kernel_ms": round(pmc["avg_ns"] * 1e-6 / k_ms, 4) if k_ms > 0 else None,
+        "source": "profiles/r2_pmc.json (rocprofv3 --pmc passes of this configuration; packed and unpacked FP32 instructions are "
+                  "counted alike, hence a range)",
+    }
+
+
+def quick_run(ctx, api, scenes, torch, dev, name, frames=1):
+    """One warm-up frame and `frames` timed frames of another workload on this GPU (the `also` dict)."""
+    wl = WORKLOADS[name]
+    W, H, spp, depth = wl["W"], wl["H"], wl["spp"], wl["depth"]
+    ctx.upload_scene(scenes.get_scene(wl["scene"], **wl["kw"]))
+    acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    rays = torch.zeros(1, dtype=torch.int64, device=dev)
+    ctx.render_into(W, H, acc, min(spp, 8), depth, seed=0xC0FFEE, rays=rays)     # warm-up
+    rays.zero_()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    k_ms = 0.0
+    for _ in range(frames):
+        ctx.render_into(W, H, acc, spp, depth, seed=0xC0FFEE, rays=rays)
+        k_ms += ctx.last_kernel_ms()[0]
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    n = int(rays.item())
+    return {"workload": wl["desc"], "ms_per_frame": round(1e3 * dt / frames, 3), "kernel_ms": round(k_ms / frames, 3),
+            "Mrays_per_s": round(n / dt / 1e6, 1), "rays_per_frame": n // frames}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,6 +163,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("RT_BENCH_WORKLOAD", "c3"), choices=sorted(WORKLOADS))
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (diagnostics only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-also", action="store_true", help="skip the short runs of the other workloads (the `also` dict)")
     args = ap.parse_args()
 
     import torch
@@ -234,6 +285,18 @@ def main():
                                        "the box hierarchy and the packed filter answer most tests without evaluating them",
                          "accumulator_GBps": round(W * H * 16 / (k_ms * 1e-3) / 1e9, 3) if k_ms > 0 else None},
         }
+        try:   # executed work from the committed PMC passes, only for the exact configuration they ran
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc.json"))).get(args.workload)
+            if pmc and world == 1 and (pmc["W"], pmc["H"], pmc["spp"]) == (W, H, spp):
+                ex = executed_work(pmc, k_ms)
+                ex["valu_insts_per_ray"] = round(pmc["counters_per_launch"]["SQ_INSTS_VALU"] * 64 / max(local_rays / max(args.steps, 1), 1), 1)
+                out["roofline"]["executed"] = ex
+        except (OSError, ValueError, KeyError) as e:
+            out["roofline"]["executed"] = {"error": str(e)[:100]}
+        if world == 1 and not args.no_also:
+            # the other single-GPU workloads, one timed frame each, so that 1080p (BASELINE.json configs[1]) and the triangle
+            # configs are driver-observed as well; their rocprof summaries are profiles/r2_<name>_*
+            out["also"] = {n: quick_run(ctx, api, scenes, torch, dev, n) for n in ("c2", "box", "c4", "c5") if n != args.workload}
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, wl)
         print(json.dumps(out), flush=True)

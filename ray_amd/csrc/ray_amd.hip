@@ -282,6 +282,8 @@ __device__ __forceinline__ bool medium_t(const float* __restrict__ b, bool is_bo
 // scan equals "smallest t, ties to the later entry", which is what the grouped scan computes. If any
 // accepted t is NaN the list order matters (a NaN closest_so_far accepts everything after it), so
 // that lane redoes the scan in list order -- rare (a ray component exactly 0 on a plane it lies in).
+// MEDIA: false = the scene has no constant_medium (the launcher knows), its code is compiled out of this instance
+template <bool MEDIA = true>
 __device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const Ray& r, double t_min, double t_max, Rng& g) {
     Hit h; h.t = t_max; h.prim = -1;
     for (int i = 0; i < sc.n_prims; ++i) {
@@ -289,7 +291,7 @@ __device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const R
         double t; bool ok;
         if (k == 0) ok = sphere_t(r, sc.sph[j], t_min, h.t, i, h.prim, &t);
         else if (k == 1) ok = rect_t(r, sc.rect_axis[j], sc.rect + 5 * j, t_min, h.t, i, h.prim, &t);
-        else if (k == 3) ok = medium_t(sc.med_bound + 6 * j, sc.med_is_box[j] != 0, sc.med_niv[j], r, g, t_min, h.t, &t);
+        else if (MEDIA && k == 3) ok = medium_t(sc.med_bound + 6 * j, sc.med_is_box[j] != 0, sc.med_niv[j], r, g, t_min, h.t, &t);
         else ok = tri_t(r, sc.tri + 16 * j, t_min, h.t, i, h.prim, &t);
         if (ok) { h.t = t; h.prim = i; }
     }
@@ -333,9 +335,13 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
 // launcher picks this instance for scenes with >= kRectFlagMin rects), 2 = choose at run time (the one-ray kernels).
 // A compile-time choice for the render kernel: the second path's code costs the 485-sphere frame 3 % when it is
 // merely present.
-template <int RECTS = 2>
+// MEDIA: 0 = no constant_medium in the scene (its code is compiled out), 1 = there is one: list-order scan only,
+// 2 = decide at run time (the one-ray kernels). A compile-time choice for the render kernel for the same reason as RECTS:
+// the medium's code merely being present costs the other workloads registers (16 VGPRs spilled to scratch).
+template <int RECTS = 2, int MEDIA = 2>
 __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, double t_min, double t_max, Rng& g, uint32_t* words RT_STAMP_PARAM) {
     Hit h; h.t = t_max; h.prim = -1;
+    if (MEDIA == 1) return closest_hit_listorder<true>(sc, r, t_min, t_max, g);
     bool ok = sc.fast_ok && ray_in_fast_range(r.o, r.d, r.dl2) && t_min == t_min && t_max == t_max;
     if (ok) {
         HitState hs;
@@ -380,7 +386,7 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
         if (!saw_nan) scan_triangles(sc, r, t_min, h, words RT_STAMP_ARG);
         ok = !saw_nan;
     }
-    if (!ok) h = closest_hit_listorder(sc, r, t_min, t_max, g);
+    if (!ok) h = closest_hit_listorder<MEDIA != 0>(sc, r, t_min, t_max, g);
     RT_STAMP(4);
     return h;
 }
@@ -540,7 +546,8 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const
         ray = make_ray(rec.p, reflected + fuzz * random_in_unit_sphere(g));
         w = rgb;
     } else if (mk == RT_MAT_DIELECTRIC) {                                   // hitPosition.h:253-287
-        double refraction_ratio = rec.front_face ? sc.mat_inv_ir[m] : sc.mat_ir[m];
+        const double inv_ir = sc.mat_inv_ir[m], ir = sc.mat_ir[m];   // both loaded: a select of the two POINTERS becomes a table in scratch
+        double refraction_ratio = rec.front_face ? inv_ir : ir;
         float cos_theta = float(__builtin_fmin(double(dot(-unit_direction, rec.normal)), 1.0));
         float sin_theta = float(sqrt64(double(1.0f - cos_theta * cos_theta)));
         bool cannot_refract = refraction_ratio * double(sin_theta) > 1.0;
@@ -662,7 +669,7 @@ struct RenderArgs {
 // refilled with one 8x8 tile from a global counter (one atomic per wave and tile).
 // PIXELS: the work items are the entries of a caller-supplied pixel list (RayView::renderOneRay's random
 // pixels, rayview.cpp:69-70) instead of the tiles of a row range.
-template <bool VERIFY, bool PIXELS = false, int RECTS = 0>
+template <bool VERIFY, bool PIXELS = false, int RECTS = 0, int MEDIA = 0>
 __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra) {
     __shared__ uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
@@ -741,10 +748,9 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
         // ---- one closest-hit scan per lane, then one bounce ------------------------------------------------
         if (path) {
             ++n_rays;
-            Hit h = closest_hit<RECTS>(sc, ray, double(0.001f), kInf, g, words RT_STAMP_ARG);   // calc.cpp:99
-            if (VERIFY) {
-                Rng gv = g;   // scenes with a constant_medium (which draws inside the scan) are rejected for VERIFY by the host
-                Hit h2 = closest_hit_listorder(sc, ray, double(0.001f), kInf, gv);
+            Hit h = closest_hit<RECTS, MEDIA>(sc, ray, double(0.001f), kInf, g, words RT_STAMP_ARG);   // calc.cpp:99
+            if (VERIFY) {   // scenes with a constant_medium (which draws inside the scan) are rejected for VERIFY by the host
+                Hit h2 = closest_hit_listorder<false>(sc, ray, double(0.001f), kInf, g);
                 if (h2.prim != h.prim || __double_as_longlong(h2.t) != __double_as_longlong(h.t)) atomicAdd(ra.mismatches, 1ull);
             }
             V3 L;
@@ -1639,7 +1645,8 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
 #endif
     if (begin_timed()) return 1;
     const bool many_rects = G().scene.n_rect >= kRectFlagMin;
-    if (verify && many_rects) hipLaunchKernelGGL((render_kernel<true, false, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    if (G().scene.n_med > 0) hipLaunchKernelGGL((render_kernel<false, false, 0, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    else if (verify && many_rects) hipLaunchKernelGGL((render_kernel<true, false, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     else if (verify) hipLaunchKernelGGL((render_kernel<true, false, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     else if (many_rects) hipLaunchKernelGGL((render_kernel<false, false, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     else hipLaunchKernelGGL((render_kernel<false, false, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
@@ -1716,7 +1723,8 @@ int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_b
     ra.pixels = d_pixels; ra.n_pixels = int(n);
     HIP_OK(hipMemsetAsync(G().counters, 0, 4, G().stream));
     if (begin_timed()) return 1;
-    if (G().scene.n_rect >= kRectFlagMin) hipLaunchKernelGGL((render_kernel<false, true, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    if (G().scene.n_med > 0) hipLaunchKernelGGL((render_kernel<false, true, 0, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    else if (G().scene.n_rect >= kRectFlagMin) hipLaunchKernelGGL((render_kernel<false, true, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     else hipLaunchKernelGGL((render_kernel<false, true, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     return finish_timed(1);
 }

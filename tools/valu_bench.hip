@@ -9,6 +9,7 @@ __global__ __launch_bounds__(256) void k(float* out, float seed) {
     float m = 1.0000001f;
     typedef float f2 __attribute__((ext_vector_type(2)));
     f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pm = {m, m};
+    double q0 = a0 + 1.0, q1 = a1 + 1.0, q2 = a2 + 1.0, q3 = a3 + 1.0, qm = 1.0000000001;
     for (int i = 0; i < N_ITER; ++i) {
       _Pragma("unroll") for (int rep = 0; rep < 4; ++rep) {
         if (MODE == 0) {   // 8 independent v_mul_f32
@@ -36,6 +37,26 @@ __global__ __launch_bounds__(256) void k(float* out, float seed) {
             asm volatile("v_alignbit_b32 %0, %0, %8, 31\n v_alignbit_b32 %1, %1, %8, 31\n v_alignbit_b32 %2, %2, %8, 31\n v_alignbit_b32 %3, %3, %8, 31\n"
                          "v_alignbit_b32 %4, %4, %8, 31\n v_alignbit_b32 %5, %5, %8, 31\n v_alignbit_b32 %6, %6, %8, 31\n v_alignbit_b32 %7, %7, %8, 31\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+        } else if (MODE >= 8) {   // FP64 and transcendental issue rates without conversions in the loop (round 2)
+            static_assert(MODE <= 16, "");
+            if (MODE == 8) asm volatile("v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4\n"
+                                        : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(qm));
+            if (MODE == 9) asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n"
+                                        : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(qm));
+            if (MODE == 10) asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n"
+                                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(qm));
+            if (MODE == 11) asm volatile("v_rcp_f64 %0, %0\n v_rcp_f64 %1, %1\n v_rcp_f64 %2, %2\n v_rcp_f64 %3, %3\n"
+                                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+            if (MODE == 12) asm volatile("v_rsq_f64 %0, %0\n v_rsq_f64 %1, %1\n v_rsq_f64 %2, %2\n v_rsq_f64 %3, %3\n"
+                                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+            if (MODE == 13) asm volatile("v_cvt_f64_f32 %0, %4\n v_cvt_f64_f32 %1, %5\n v_cvt_f64_f32 %2, %6\n v_cvt_f64_f32 %3, %7\n"
+                                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+            if (MODE == 14) asm volatile("v_cvt_f32_f64 %0, %4\n v_cvt_f32_f64 %1, %5\n v_cvt_f32_f64 %2, %6\n v_cvt_f32_f64 %3, %7\n"
+                                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(q0), "v"(q1), "v"(q2), "v"(q3));
+            if (MODE == 15) asm volatile("v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
+                                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+            if (MODE == 16) asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3\n"
+                                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
         } else if (MODE == 7) {   // 8 v_mul_f64? use 4 v_fma_f64
             double d0 = a0, d1 = a1, d2 = a2, d3 = a3, dm = m;
             asm volatile("v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4\n"
@@ -44,6 +65,7 @@ __global__ __launch_bounds__(256) void k(float* out, float seed) {
         }
       }
     }
+    a7 += float(q0 + q1 + q2 + q3);
     float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
     if (r == 12345.678f) out[0] = r;
 }
@@ -58,7 +80,11 @@ void run(const char* name, int ops_per_iter, float* d) {
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
     double lane_ops = double(grid) * 256 * N_ITER * 4.0 * ops_per_iter;
-    printf("%-28s %8.3f ms  %7.2f T lane-ops/s (elementwise results/s)\n", name, ms, lane_ops / (ms * 1e-3) / 1e12);
+    // cycles per wave-instruction on one SIMD: 8 waves per SIMD share it; clock from the device
+    int dev = 0, khz = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev);
+    const double instr_per_wave = double(N_ITER) * 4.0 * (MODE == 1 || MODE == 3 || MODE == 5 ? ops_per_iter / 2 : ops_per_iter);
+    const double cyc = ms * 1e-3 * khz * 1e3 / (instr_per_wave * 8.0);
+    printf("%-28s %8.3f ms  %7.2f T lane-ops/s  %6.2f cycles per wave-instruction (8 waves/SIMD, %d MHz)\n", name, ms, lane_ops / (ms * 1e-3) / 1e12, cyc, khz / 1000);
 }
 int main() {
     float* d; hipMalloc(&d, 4);
@@ -70,5 +96,14 @@ int main() {
     run<5>("v_pk_fma_f32 x4 (8 fma)", 8, d);
     run<6>("v_alignbit_b32 x8", 8, d);
     run<7>("v_fma_f64 x4 (+cvt)", 4, d);
+    run<8>("v_fma_f64 x4", 4, d);
+    run<9>("v_mul_f64 x4", 4, d);
+    run<10>("v_add_f64 x4", 4, d);
+    run<11>("v_rcp_f64 x4", 4, d);
+    run<12>("v_rsq_f64 x4", 4, d);
+    run<13>("v_cvt_f64_f32 x4", 4, d);
+    run<14>("v_cvt_f32_f64 x4", 4, d);
+    run<15>("v_rcp_f32 x4", 4, d);
+    run<16>("v_sqrt_f32 x4", 4, d);
     return 0;
 }
