@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <string>
 #include <vector>
@@ -55,6 +56,12 @@ struct DevScene {
     float rect_extent;                     // max |coordinate| of the rects
     const float* __restrict__ rect_bbox;   // [12 per pair of batches] the same around every batch of 16 rects (scenes with >= kRectFlagMin rects:
                                            // the rects are then in spatially compact batches, not sorted by axis)
+    const float4* __restrict__ tbvh;       // triangle BVH (null: none), 4 float4 per node: the two children's boxes relative to tg's g as
+                                           // (lo.x0, lo.x1, lo.y0, lo.y1), (lo.z0, lo.z1, hi.x0, hi.x1), (hi.y0, hi.y1, hi.z0, hi.z1), then
+                                           // (child 0, child 1, -, -) as int bits: >= 0 inner node, < 0 leaf ~item (an item: tri slots 2i, 2i + 1)
+    float tri_extent;                      // max |box coordinate| of the BVH (relative to g)
+    int tbvh_leaf_items;                   // a leaf ~s is the run of item slots [s, s + tbvh_leaf_items) (1 up to 32k items; consecutive
+                                           // slots are spatially compact, see build_group)
     int n_med;                             // constant_medium primitives (shapes.h:374-455); any of them: list-order scan only
     const float* __restrict__ med_bound;   // [n_med][6] sphere boundary: cx, cy, cz, r, -, - ; box boundary: p0 xyz, p1 xyz
     const double* __restrict__ med_niv;    // [n_med] neg_inv_density
@@ -328,6 +335,55 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     }
 }
 
+// Triangles of one ray through the BVH (the acceleration structure the reference planned over its
+// aabb / bounding_box hooks, shapes.h:14-44, hitPosition.cpp:24-53, and never shipped). Every lane walks the tree on its
+// own: a node holds the boxes of its two children, both tested with one packed slab test (box_pair_v); a leaf is one
+// item of up to two triangles, tested with tri_t. The walk is conservative, so the result is still hitFromList's: a leaf
+// box encloses its triangles' bounding spheres, every accepted hit point lies inside its triangle's sphere by definition of
+// the primitive (ray_amd_tri.h), and the boxes are widened by m = 2e-5 (|o| + extent), far above the FP32 rounding of the
+// hit point, of the slab arithmetic and of the clamp of tiny direction components (< 1e-6 of that scale).
+// tri_t keeps the list-order tie rule through the flattened index, so the visiting order does not matter.
+// The stack (node indices) is the lane's column of the flag words in LDS: at most kMaskWords entries (the builder
+// balances the tree and refuses scenes that would need more).
+__device__ __forceinline__ void scan_triangles_bvh(const DevScene& sc, const Ray& r, double t_min, Hit& h, uint32_t* words) {
+    auto visit = [&](int item) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int slot = 2 * item + hh;
+            const int idx = sc.tri_prim[slot];
+            double t;
+            if (idx >= 0 && tri_t(r, sc.tri + 16 * slot, t_min, h.t, idx, h.prim, &t)) { h.t = t; h.prim = idx; }
+        }
+    };
+    const V3 orel = r.o - v3(sc.tg.gx, sc.tg.gy, sc.tg.gz);
+    const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(orel.x), __builtin_fabsf(orel.y)), __builtin_fabsf(orel.z));
+    FilterRay br;
+    set_box_ray(br, orel, r.d, r.dl2, 2.0e-5f * (omax + sc.tri_extent) + 1.0e-30f, t_min);
+    int node = 0, sp = 0;
+    for (;;) {
+        const float4* __restrict__ q = sc.tbvh + 4 * node;
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+        bool n0, n1;
+        float e0, e1;
+        box_pair_v(br, __double2float_ru(h.t), f2{q0.x, q0.y}, f2{q0.z, q0.w}, f2{q1.x, q1.y}, f2{q1.z, q1.w}, f2{q2.x, q2.y}, f2{q2.z, q2.w}, n0, n1, e0, e1);
+        const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+        if (n0 && c0 < 0) { for (int k = 0; k < sc.tbvh_leaf_items; ++k) visit(~c0 + k); n0 = false; }
+        if (n1 && c1 < 0) { for (int k = 0; k < sc.tbvh_leaf_items; ++k) visit(~c1 + k); n1 = false; }   // tested against the t range before the first leaf: a superset
+        if (n0 && n1) {                                    // nearer child first, the other one on the stack
+            const bool first0 = e0 <= e1;
+            words[sp * kScanBlock] = uint32_t(first0 ? c1 : c0);
+            ++sp;
+            node = first0 ? c0 : c1;
+        } else if (n0) node = c0;
+        else if (n1) node = c1;
+        else {
+            if (sp == 0) break;
+            --sp;
+            node = int(words[sp * kScanBlock]);
+        }
+    }
+}
+
 // Fast scan: spheres through rt_scan.hpp (filter + exact), then rects and triangles. Lanes whose ray
 // is outside the fast range (non-finite, huge, zero direction), a scene that is, or a NaN t from a
 // rect, fall back to the list-order scan, which is the reference loop itself.
@@ -338,7 +394,9 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
 // MEDIA: 0 = no constant_medium in the scene (its code is compiled out), 1 = there is one: list-order scan only,
 // 2 = decide at run time (the one-ray kernels). A compile-time choice for the render kernel for the same reason as RECTS:
 // the medium's code merely being present costs the other workloads registers (16 VGPRs spilled to scratch).
-template <int RECTS = 2, int MEDIA = 2>
+// TRIS: 0 = the triangle group through the flat box / filter / walk levels, 1 = through the BVH (the launcher picks it
+// when rt_upload_scene built one), 2 = decide at run time.
+template <int RECTS = 2, int MEDIA = 2, int TRIS = 2>
 __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, double t_min, double t_max, Rng& g, uint32_t* words RT_STAMP_PARAM) {
     Hit h; h.t = t_max; h.prim = -1;
     if (MEDIA == 1) return closest_hit_listorder<true>(sc, r, t_min, t_max, g);
@@ -383,7 +441,10 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
             scan_rects<1>(sc.rect, sc.rect_f, sc.rect_prim, sc.n_rect_xy, sc.n_rect_xy + sc.n_rect_xz, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
             scan_rects<2>(sc.rect, sc.rect_f, sc.rect_prim, sc.n_rect_xy + sc.n_rect_xz, sc.n_rect, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
         }
-        if (!saw_nan) scan_triangles(sc, r, t_min, h, words RT_STAMP_ARG);
+        if (!saw_nan) {
+            if (TRIS == 1 || (TRIS == 2 && sc.tbvh != nullptr)) scan_triangles_bvh(sc, r, t_min, h, words);
+            else scan_triangles(sc, r, t_min, h, words RT_STAMP_ARG);
+        }
         ok = !saw_nan;
     }
     if (!ok) h = closest_hit_listorder<MEDIA != 0>(sc, r, t_min, t_max, g);
@@ -669,7 +730,7 @@ struct RenderArgs {
 // refilled with one 8x8 tile from a global counter (one atomic per wave and tile).
 // PIXELS: the work items are the entries of a caller-supplied pixel list (RayView::renderOneRay's random
 // pixels, rayview.cpp:69-70) instead of the tiles of a row range.
-template <bool VERIFY, bool PIXELS = false, int RECTS = 0, int MEDIA = 0>
+template <bool VERIFY, bool PIXELS = false, int RECTS = 0, int MEDIA = 0, int TRIS = 0>
 __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra) {
     __shared__ uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
@@ -748,7 +809,7 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
         // ---- one closest-hit scan per lane, then one bounce ------------------------------------------------
         if (path) {
             ++n_rays;
-            Hit h = closest_hit<RECTS, MEDIA>(sc, ray, double(0.001f), kInf, g, words RT_STAMP_ARG);   // calc.cpp:99
+            Hit h = closest_hit<RECTS, MEDIA, TRIS>(sc, ray, double(0.001f), kInf, g, words RT_STAMP_ARG);   // calc.cpp:99
             if (VERIFY) {   // scenes with a constant_medium (which draws inside the scan) are rejected for VERIFY by the host
                 Hit h2 = closest_hit_listorder<false>(sc, ray, double(0.001f), kInf, g);
                 if (h2.prim != h.prim || __double_as_longlong(h2.t) != __double_as_longlong(h.t)) atomicAdd(ra.mismatches, 1ull);
@@ -1274,6 +1335,7 @@ int rt_upload_scene(const RtScene* s) {
     std::vector<double> rect; std::vector<int> rect_axis, rect_prim;
     std::vector<float> tri; std::vector<int> tri_prim;
     std::vector<float> med_bound; std::vector<double> med_niv; std::vector<int> med_is_box;
+    std::vector<float> tbvh_nodes; float tri_extent = 0.0f; int tbvh_leaf_items = 1;
     std::vector<int> prim_kind(s->n_prims), prim_local(s->n_prims), prim_mat(s->n_prims);
     for (int i = 0; i < s->n_prims; ++i) {
         const double* d = s->prim_data + size_t(i) * RT_PRIM_STRIDE;
@@ -1401,6 +1463,93 @@ int rt_upload_scene(const RtScene* s) {
             }
         }
         tri.swap(tri2); tri_prim.swap(prim2);
+        // BVH over the items (scan_triangles_bvh): balanced median splits along the widest axis of the items' centres, a
+        // leaf per item, the box of a leaf around the item's bounding sphere (the radius the filter uses, a hair wider
+        // than the one tri_t tests against), relative to the group's reference point, rounded outwards.
+        // leaf = an aligned run of L consecutive item slots (consecutive slots are spatially compact: exact group in list
+        // order, filter group in kd order); L = 1 unless the tree would need more than kMaskWords - 1 levels
+        size_t n_real = 0;
+        for (int it : tgb.slot_item) n_real += it >= 0 ? 1 : 0;
+        int L = 1;
+        while ((tgb.slot_item.size() + L - 1) / L > (size_t(1) << (kMaskWords - 1)) && L < 16) L *= 2;
+        std::vector<int> leaves;
+        for (size_t sl = 0; sl < tgb.slot_item.size(); sl += L) {
+            bool any = false;
+            for (size_t k = sl; k < std::min(tgb.slot_item.size(), sl + L); ++k) any = any || tgb.slot_item[k] >= 0;
+            if (any) leaves.push_back(int(sl));
+        }
+        // OFF by default: measured against the flat chunk / word / batch levels the per-lane walk is 1.1x to 2.4x slower from
+        // 2.4k to 400k triangles (tools/bvh_crossover.py). RT_TRI_BVH_MIN=<items> switches it on for scenes
+        // of at least that many items (the tests force it onto tiny scenes with 1).
+        int bvh_min = 0x7fffffff;
+        if (const char* e = getenv("RT_TRI_BVH_MIN")) bvh_min = atoi(e);
+        if (finite && int(n_real) >= bvh_min && !leaves.empty() && leaves.size() <= (size_t(1) << (kMaskWords - 1))) {
+            const double g3[3] = {double(tgb.fg.gx), double(tgb.fg.gy), double(tgb.fg.gz)};
+            auto down = [](double v) { float f = float(v); return double(f) > v ? std::nextafterf(f, -INFINITY) : f; };
+            auto up = [](double v) { float f = float(v); return double(f) < v ? std::nextafterf(f, INFINITY) : f; };
+            struct Box { float lo[3], hi[3]; };
+            auto leaf_box = [&](int sl0) {
+                Box bx;
+                for (int k = 0; k < 3; ++k) { bx.lo[k] = INFINITY; bx.hi[k] = -INFINITY; }
+                for (size_t sl = size_t(sl0); sl < std::min(tgb.slot_item.size(), size_t(sl0) + L); ++sl) {
+                    if (tgb.slot_item[sl] < 0) continue;
+                    const float4 b = bound[tgb.slot_item[sl]];
+                    const double rr = std::sqrt(double(r2k[tgb.slot_item[sl]])) * 1.000001;
+                    const double c[3] = {b.x, b.y, b.z};
+                    for (int k = 0; k < 3; ++k) { bx.lo[k] = std::min(bx.lo[k], down(c[k] - g3[k] - rr)); bx.hi[k] = std::max(bx.hi[k], up(c[k] - g3[k] + rr)); }
+                }
+                return bx;
+            };
+            auto leaf_centre = [&](int sl0, int k) {     // centre of the run's first real item: a sort key, nothing more
+                for (size_t sl = size_t(sl0); sl < std::min(tgb.slot_item.size(), size_t(sl0) + L); ++sl) {
+                    if (tgb.slot_item[sl] < 0) continue;
+                    const float4 b = bound[tgb.slot_item[sl]];
+                    return k == 0 ? b.x : (k == 1 ? b.y : b.z);
+                }
+                return 0.0f;
+            };
+            std::vector<float> nodes;   // 16 floats per node
+            float extent = 0.0f;
+            // returns the child reference of the subtree over leaves[lo, hi) and its box
+            std::function<int(int, int, Box&)> build = [&](int lo, int hi, Box& out) -> int {
+                if (hi - lo == 1) { out = leaf_box(leaves[lo]); return ~leaves[lo]; }
+                float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                auto centre = [&](int sl, int k) { return leaf_centre(sl, k); };
+                for (int q = lo; q < hi; ++q) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], centre(leaves[q], k)); mx[k] = std::max(mx[k], centre(leaves[q], k)); }
+                int ax = 0;
+                for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
+                const int mid = lo + (hi - lo) / 2;
+                std::nth_element(leaves.begin() + lo, leaves.begin() + mid, leaves.begin() + hi, [&](int a, int b) {
+                    const float ca = centre(a, ax), cb = centre(b, ax);
+                    return ca < cb || (ca == cb && a < b);
+                });
+                const int me = int(nodes.size() / 16);
+                nodes.resize(nodes.size() + 16, 0.0f);
+                Box b0, b1;
+                const int c0 = build(lo, mid, b0), c1 = build(mid, hi, b1);
+                float* n = &nodes[size_t(me) * 16];
+                n[0] = b0.lo[0]; n[1] = b1.lo[0]; n[2] = b0.lo[1]; n[3] = b1.lo[1]; n[4] = b0.lo[2]; n[5] = b1.lo[2];
+                n[6] = b0.hi[0]; n[7] = b1.hi[0]; n[8] = b0.hi[1]; n[9] = b1.hi[1]; n[10] = b0.hi[2]; n[11] = b1.hi[2];
+                memcpy(&n[12], &c0, 4); memcpy(&n[13], &c1, 4);
+                for (int k = 0; k < 3; ++k) {
+                    out.lo[k] = std::min(b0.lo[k], b1.lo[k]); out.hi[k] = std::max(b0.hi[k], b1.hi[k]);
+                    extent = std::max(extent, std::max(std::fabs(out.lo[k]), std::fabs(out.hi[k])));
+                }
+                return me;
+            };
+            Box root;
+            if (leaves.size() == 1) {       // a root needs two children: the one leaf twice (the second visit changes nothing)
+                root = leaf_box(leaves[0]);
+                const int c = ~leaves[0];
+                nodes.assign(16, 0.0f);
+                for (int k = 0; k < 3; ++k) { nodes[2 * k] = nodes[2 * k + 1] = root.lo[k]; nodes[6 + 2 * k] = nodes[7 + 2 * k] = root.hi[k];
+                                              extent = std::max(extent, std::max(std::fabs(root.lo[k]), std::fabs(root.hi[k]))); }
+                memcpy(&nodes[12], &c, 4); memcpy(&nodes[13], &c, 4);
+            } else {
+                build(0, int(leaves.size()), root);
+            }
+            tbvh_nodes.swap(nodes); tri_extent = extent; tbvh_leaf_items = L;
+        }
     }
 
     int n_rect_axis[3] = {0, 0, 0};
@@ -1488,6 +1637,11 @@ int rt_upload_scene(const RtScene* s) {
     if (upload(tgb.fx, &tgb.fg.fx) || upload(tgb.fy, &tgb.fg.fy) || upload(tgb.fz, &tgb.fg.fz) || upload(tgb.fk, &tgb.fg.fk) ||
         upload(tgb.bnd, &tgb.fg.bnd) || upload(tgb.wbnd, &tgb.fg.wbnd) || upload(tgb.cbnd, &tgb.fg.cbnd)) return 1;
     tgb.fg.fq = nullptr;
+    if (!tbvh_nodes.empty() && finite) {
+        const float* dn = nullptr;
+        if (upload(tbvh_nodes, &dn)) return 1;
+        ds.tbvh = reinterpret_cast<const float4*>(dn); ds.tri_extent = tri_extent; ds.tbvh_leaf_items = tbvh_leaf_items;
+    }
     ds.n_med = int(med_niv.size());
     if (upload(med_bound, &ds.med_bound) || upload(med_niv, &ds.med_niv) || upload(med_is_box, &ds.med_is_box)) return 1;
     // a constant_medium draws a random number INSIDE hitFromList's loop, for every ray that crosses its boundary within
@@ -1645,7 +1799,10 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
 #endif
     if (begin_timed()) return 1;
     const bool many_rects = G().scene.n_rect >= kRectFlagMin;
+    const bool bvh = G().scene.tbvh != nullptr && !many_rects;   // (a scene with many rects AND a triangle BVH takes the flat triangle path)
     if (G().scene.n_med > 0) hipLaunchKernelGGL((render_kernel<false, false, 0, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    else if (verify && bvh) hipLaunchKernelGGL((render_kernel<true, false, 0, 0, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    else if (bvh) hipLaunchKernelGGL((render_kernel<false, false, 0, 0, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     else if (verify && many_rects) hipLaunchKernelGGL((render_kernel<true, false, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     else if (verify) hipLaunchKernelGGL((render_kernel<true, false, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     else if (many_rects) hipLaunchKernelGGL((render_kernel<false, false, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
@@ -1724,6 +1881,7 @@ int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_b
     HIP_OK(hipMemsetAsync(G().counters, 0, 4, G().stream));
     if (begin_timed()) return 1;
     if (G().scene.n_med > 0) hipLaunchKernelGGL((render_kernel<false, true, 0, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    else if (G().scene.tbvh != nullptr && G().scene.n_rect < kRectFlagMin) hipLaunchKernelGGL((render_kernel<false, true, 0, 0, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     else if (G().scene.n_rect >= kRectFlagMin) hipLaunchKernelGGL((render_kernel<false, true, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     else hipLaunchKernelGGL((render_kernel<false, true, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     return finish_timed(1);

@@ -280,6 +280,35 @@ __device__ __forceinline__ void box_pair(const FilterRay& fr, float t_hi, f2 LX,
     }
 }
 
+// The same slab test with the two boxes in VGPRs (every lane looks at its own BVH node) and the entry parameters returned.
+template <int SC, int SA>
+__device__ __forceinline__ f2 pk_fma_cc_v(f2 c, f2 x, f2 a) {
+    f2 r;
+    if (SC == 0 && SA == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(r) : "v"(c), "v"(x), "v"(a));
+    else if (SC == 0 && SA == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,1,1]" : "=v"(r) : "v"(c), "v"(x), "v"(a));
+    else if (SC == 1 && SA == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(c), "v"(x), "v"(a));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(c), "v"(x), "v"(a));
+    return r;
+}
+__device__ __forceinline__ void box_pair_v(const FilterRay& fr, float t_hi, f2 LX, f2 LY, f2 LZ, f2 HX, f2 HY, f2 HZ, bool& n0, bool& n1, float& e0,
+                                           float& e1) {
+    const f2 x1 = pk_fma_cc_v<0, 0>(fr.I01, LX, fr.CX), x2 = pk_fma_cc_v<0, 1>(fr.I01, HX, fr.CX);
+    const f2 y1 = pk_fma_cc_v<1, 0>(fr.I01, LY, fr.CY), y2 = pk_fma_cc_v<1, 1>(fr.I01, HY, fr.CY);
+    const f2 z1 = pk_fma_cc_v<0, 0>(fr.I2, LZ, fr.CZ), z2 = pk_fma_cc_v<0, 1>(fr.I2, HZ, fr.CZ);
+    {
+        const float tn = vmax3(vmin(x1.x, x2.x), vmin(y1.x, y2.x), vmin(z1.x, z2.x));
+        const float tf = vmin3(vmax(x1.x, x2.x), vmax(y1.x, y2.x), vmax(z1.x, z2.x));
+        e0 = vmax(tn, fr.t_lo);
+        n0 = e0 <= vmin(tf, t_hi);
+    }
+    {
+        const float tn = vmax3(vmin(x1.y, x2.y), vmin(y1.y, y2.y), vmin(z1.y, z2.y));
+        const float tf = vmin3(vmax(x1.y, x2.y), vmax(y1.y, y2.y), vmax(z1.y, z2.y));
+        e1 = vmax(tn, fr.t_lo);
+        n1 = e1 <= vmin(tf, t_hi);
+    }
+}
+
 // Level 0, chunks: does any lane of the wave need chunk ci (wave-uniform answer)? Groups of one chunk skip the test.
 __device__ __forceinline__ bool chunk_needed(const FilterGroup& fg, const FilterRay& fr, float t_hi, int ci) {
     if ((fg.n_fpairs >> 5) <= fg.chunk_words) return true;

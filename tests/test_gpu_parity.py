@@ -893,3 +893,65 @@ def test_constant_medium_through_the_c_abi(rt):
     a, r = rt.render(64, 36, 4, 8, seed=3)
     oa, orr = O.render(surf, 64, 36, 4, 8, rng_mode=1, seed64=3, math_mode=1)
     assert r == orr and O.same_values(a, oa)
+
+
+def test_triangle_bvh_forced_on_small_and_odd_scenes(rt):
+    """The per-lane triangle BVH (scan_triangles_bvh) is an alternative to the flat box levels that
+    measures slower and is therefore off unless RT_TRI_BVH_MIN=<items> asks for it. RT_TRI_BVH_MIN=1 forces it onto tiny
+    and odd-sized soups (1, 2, 3, 5 ... triangles: the one-leaf root, unbalanced halves), a huge value keeps it off: both
+    paths must give the oracle's hitFromList, the analytic known answers included; and a frame of the 9800-triangle
+    mesh through the BVH must equal the list-order loop ray for ray (RT_RENDER_VERIFY) and the flat path's frame."""
+    import os
+    import tri_kat
+    rng = np.random.default_rng(77)
+    mats = [scenes.Material(scenes.MAT_LAMBERTIAN, (0.5, 0.5, 0.5))]
+    try:
+        for bvh_min in ("1", "1000000"):
+            os.environ["RT_TRI_BVH_MIN"] = bvh_min
+
+            def hit_rays(sc, ro, rd, t_min, t_max):
+                rt.upload_scene(sc, set_camera=False)
+                return rt.hit_rays(ro, rd, t_min, t_max)
+            tri_kat.check_unit_triangle(hit_rays)
+            tri_kat.check_general_triangles(hit_rays, seed=8, n_tri=10)
+            tri_kat.check_triangle_pair_equals_rectangle(hit_rays)
+            for n_tri in (1, 2, 3, 5, 8, 63, 130):
+                shapes, cents = [], []
+                for _ in range(n_tri):
+                    p = rng.uniform(-6, 6, 3)
+                    e1, e2 = rng.standard_normal(3) * 0.8, rng.standard_normal(3) * 0.8
+                    v = [np.float32(p), np.float32(p + e1), np.float32(p + e2)]
+                    shapes.append(scenes.Shape("triangle", tuple(float(t) for t in (*v[0], *v[1], *v[2])), 0))
+                    cents.append((v[0] + v[1] + v[2]) / 3)
+                shapes.append(scenes.Shape("sphere", (0.0, -50.0, 0.0, 44.0), 0))        # something behind the soup
+                sc = scenes.Scene(mats, shapes, None, scenes.rayview_camera())
+                rt.upload_scene(sc, set_camera=False)
+                n = 4000
+                cents_a = np.array(cents, np.float64)
+                ro = rng.uniform(-15, 15, (n, 3))
+                rd = cents_a[rng.integers(0, n_tri, n)] + rng.uniform(-0.3, 0.3, (n, 3)) - ro
+                rd[: n // 4] = rng.standard_normal((n // 4, 3))
+                rd[::37, 1] = 0.0
+                ro, rd = ro.astype(np.float32), rd.astype(np.float32)
+                for t_min, t_max in [(0.001, np.inf), (-4.0, 30.0)]:
+                    got = rt.hit_rays(ro, rd, t_min, t_max)
+                    ref = O.hit_rays(sc, ro, rd, t_min, t_max)
+                    assert np.array_equal(got[0], ref[0]), (bvh_min, n_tri)
+                    assert O.bits_equal(got[1], ref[1])
+                    for a, b in zip(got[2:], ref[2:]):
+                        assert O.same_values(a, b)
+        sc = scenes.get_scene("tris", n=71)
+        frames = {}
+        for bvh_min in ("1", "1000000000"):
+            os.environ["RT_TRI_BVH_MIN"] = bvh_min
+            rt.upload_scene(sc)
+            frames[bvh_min], rays = rt.render(480, 270, 2, 8, seed=0xBEEF, flags=4)
+            assert rt.verify_mismatches() == 0 and rays > 480 * 270 * 2
+        assert O.same_values(frames["1"], frames["1000000000"])
+        big = scenes.get_scene("tris", n=200)              # 79k triangles: two item slots per leaf
+        os.environ["RT_TRI_BVH_MIN"] = "1"
+        rt.upload_scene(big)
+        _, rays = rt.render(480, 270, 1, 8, seed=0xBEEF, flags=4)
+        assert rt.verify_mismatches() == 0 and rays > 480 * 270
+    finally:
+        os.environ.pop("RT_TRI_BVH_MIN", None)
