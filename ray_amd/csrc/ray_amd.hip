@@ -1336,6 +1336,7 @@ int rt_upload_scene(const RtScene* s) {
     std::vector<float> tri; std::vector<int> tri_prim;
     std::vector<float> med_bound; std::vector<double> med_niv; std::vector<int> med_is_box;
     std::vector<float> tbvh_nodes; float tri_extent = 0.0f; int tbvh_leaf_items = 1;
+    std::vector<float> sbvh_nodes;
     std::vector<int> prim_kind(s->n_prims), prim_local(s->n_prims), prim_mat(s->n_prims);
     for (int i = 0; i < s->n_prims; ++i) {
         const double* d = s->prim_data + size_t(i) * RT_PRIM_STRIDE;
@@ -1405,6 +1406,62 @@ int rt_upload_scene(const RtScene* s) {
             fq.push_back(make_float4(s0.z, s1.z, s0.w * s0.w, s1.w * s1.w));
         }
         sph.swap(sph2); sph_prim.swap(prim2);
+#ifdef RT_EXPERIMENT_SPHERE_BVH
+        {   // BVH over the sphere pairs (experiment): balanced median splits, leaf = pair, box around both spheres, relative to g
+            std::vector<int> leaves;
+            for (size_t pr = size_t(sgb.fg.n_ewords) * 32; pr < sph.size() / 2; ++pr)   // the filter group's pairs; the exact group is visited first as always
+                if (sph_prim[2 * pr] >= 0 || sph_prim[2 * pr + 1] >= 0) leaves.push_back(int(pr));
+            const double g3[3] = {double(sgb.fg.gx), double(sgb.fg.gy), double(sgb.fg.gz)};
+            struct Box { float lo[3], hi[3]; };
+            auto down = [](double v) { float f = float(v); return double(f) > v ? std::nextafterf(f, -INFINITY) : f; };
+            auto up = [](double v) { float f = float(v); return double(f) < v ? std::nextafterf(f, INFINITY) : f; };
+            auto leaf_box = [&](int pr) {
+                Box bx;
+                for (int k = 0; k < 3; ++k) { bx.lo[k] = INFINITY; bx.hi[k] = -INFINITY; }
+                for (int hh = 0; hh < 2; ++hh) {
+                    if (sph_prim[2 * pr + hh] < 0) continue;
+                    const float4 b = sph[2 * pr + hh];
+                    const double c[3] = {b.x, b.y, b.z}, rr = std::fabs(double(b.w)) * 1.000001;
+                    for (int k = 0; k < 3; ++k) { bx.lo[k] = std::min(bx.lo[k], down(c[k] - g3[k] - rr)); bx.hi[k] = std::max(bx.hi[k], up(c[k] - g3[k] + rr)); }
+                }
+                return bx;
+            };
+            auto centre = [&](int pr, int k) { const float4 b = sph[2 * pr + (sph_prim[2 * pr] >= 0 ? 0 : 1)]; return k == 0 ? b.x : (k == 1 ? b.y : b.z); };
+            std::vector<float> nodes;
+            float extent = 0.0f;
+            std::function<int(int, int, Box&)> build = [&](int lo, int hi, Box& out) -> int {
+                if (hi - lo == 1) { out = leaf_box(leaves[lo]); return ~leaves[lo]; }
+                float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (int q = lo; q < hi; ++q) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], centre(leaves[q], k)); mx[k] = std::max(mx[k], centre(leaves[q], k)); }
+                int ax = 0;
+                for (int k = 1; k < 3; ++k) if (mx[k] - mn[k] > mx[ax] - mn[ax]) ax = k;
+                const int mid = lo + (hi - lo) / 2;
+                std::nth_element(leaves.begin() + lo, leaves.begin() + mid, leaves.begin() + hi, [&](int a, int b) {
+                    const float ca = centre(a, ax), cb = centre(b, ax);
+                    return ca < cb || (ca == cb && a < b);
+                });
+                const int me = int(nodes.size() / 16);
+                nodes.resize(nodes.size() + 16, 0.0f);
+                Box b0, b1;
+                const int c0 = build(lo, mid, b0), c1 = build(mid, hi, b1);
+                float* n = &nodes[size_t(me) * 16];
+                n[0] = b0.lo[0]; n[1] = b1.lo[0]; n[2] = b0.lo[1]; n[3] = b1.lo[1]; n[4] = b0.lo[2]; n[5] = b1.lo[2];
+                n[6] = b0.hi[0]; n[7] = b1.hi[0]; n[8] = b0.hi[1]; n[9] = b1.hi[1]; n[10] = b0.hi[2]; n[11] = b1.hi[2];
+                memcpy(&n[12], &c0, 4); memcpy(&n[13], &c1, 4);
+                for (int k = 0; k < 3; ++k) {
+                    out.lo[k] = std::min(b0.lo[k], b1.lo[k]); out.hi[k] = std::max(b0.hi[k], b1.hi[k]);
+                    extent = std::max(extent, std::max(std::fabs(out.lo[k]), std::fabs(out.hi[k])));
+                }
+                return me;
+            };
+            sgb.fg.sbvh = nullptr; sgb.fg.sbvh_extent = 0.0f;
+            if (finite && leaves.size() >= 8 && leaves.size() <= (size_t(1) << (kMaskWords - 1))) {
+                Box root;
+                build(0, int(leaves.size()), root);
+                sbvh_nodes.swap(nodes); sgb.fg.sbvh_extent = extent;
+            }
+        }
+#endif
     }
     {
         // Filter items of the triangle group: ONE bounding sphere per item of up to two triangles. Two
@@ -1637,6 +1694,14 @@ int rt_upload_scene(const RtScene* s) {
     if (upload(tgb.fx, &tgb.fg.fx) || upload(tgb.fy, &tgb.fg.fy) || upload(tgb.fz, &tgb.fg.fz) || upload(tgb.fk, &tgb.fg.fk) ||
         upload(tgb.bnd, &tgb.fg.bnd) || upload(tgb.wbnd, &tgb.fg.wbnd) || upload(tgb.cbnd, &tgb.fg.cbnd)) return 1;
     tgb.fg.fq = nullptr;
+#ifdef RT_EXPERIMENT_SPHERE_BVH
+    tgb.fg.sbvh = nullptr; tgb.fg.sbvh_extent = 0.0f;
+    if (!sbvh_nodes.empty() && finite) {
+        const float* dn = nullptr;
+        if (upload(sbvh_nodes, &dn)) return 1;
+        sgb.fg.sbvh = reinterpret_cast<const float4*>(dn);
+    }
+#endif
     if (!tbvh_nodes.empty() && finite) {
         const float* dn = nullptr;
         if (upload(tbvh_nodes, &dn)) return 1;

@@ -60,6 +60,12 @@ struct FilterGroup {
     float gx, gy, gz;                // reference point of the filter group
     float cmax, r2max;               // max |centre - g| (rounded up), max r^2 over the filter group
     float margin_k;                  // M = margin_k * a * (S^2 + So^2 + r2max)
+#ifdef RT_EXPERIMENT_SPHERE_BVH
+    // Experiment (tools/build_exp_sphere_bvh.sh): every lane walks a BVH over the sphere PAIRS of the filter
+    // group instead of the wave-level box / filter levels. Nodes as in scan_triangles_bvh; a leaf ~p is pair p.
+    const float4* __restrict__ sbvh;
+    float sbvh_extent;
+#endif
 };
 constexpr float kMarginKTri = 160.0f * 5.9604644775390625e-08f;   // + the FP32 hit point's rounding (ray_amd_tri.h)
 
@@ -460,6 +466,43 @@ __device__ __forceinline__ void scan_spheres(const FilterGroup& sg, const int* _
         if (h.dD >= 0.0f) { resolve_exact(a, t_min, t_max, h, false, 0.0f, 0.0f, -1); }
         return;
     }
+#ifdef RT_EXPERIMENT_SPHERE_BVH
+    if (sg.sbvh != nullptr) {
+        // Conservative boxes: a pair's box encloses both spheres; the reference accepts a root only if the line passes
+        // within sqrt(r^2 + 23 u (|oc|^2 + r^2)) of the centre (|D_ref - D*| <= 23 u a (|oc|^2 + r^2)), i.e. within
+        // r + 1.17e-3 |oc| with |oc| <= 1.74 (|o - g|_inf + extent); widened by m = 2.1e-3 (|o - g|_inf + extent), which also covers the
+        // slab arithmetic. The exact group (the ground sphere) has been visited above and is not in the tree: its size would set the margin.
+        const V3 orel = o - v3(sg.gx, sg.gy, sg.gz);
+        const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(orel.x), __builtin_fabsf(orel.y)), __builtin_fabsf(orel.z));
+        FilterRay br;
+        set_box_ray(br, orel, d, a, 2.1e-3f * (omax + sg.sbvh_extent) + 1.0e-30f, t_min);
+        int node = 0, sp = 0;
+        for (;;) {
+            const float4* __restrict__ q = sg.sbvh + 4 * node;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            bool n0, n1;
+            float e0, e1;
+            box_pair_v(br, h.bhi, f2{q0.x, q0.y}, f2{q0.z, q0.w}, f2{q1.x, q1.y}, f2{q1.z, q1.w}, f2{q2.x, q2.y}, f2{q2.z, q2.w}, n0, n1, e0, e1);
+            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            if (n0 && c0 < 0) { visit(~c0); n0 = false; }
+            if (n1 && c1 < 0) { visit(~c1); n1 = false; }
+            if (n0 && n1) {
+                const bool first0 = e0 <= e1;
+                words[sp * kScanBlock] = uint32_t(first0 ? c1 : c0);
+                ++sp;
+                node = first0 ? c0 : c1;
+            } else if (n0) node = c0;
+            else if (n1) node = c1;
+            else {
+                if (sp == 0) break;
+                --sp;
+                node = int(words[sp * kScanBlock]);
+            }
+        }
+        if (h.dD >= 0.0f) { resolve_exact(a, t_min, t_max, h, false, 0.0f, 0.0f, -1); }
+        return;
+    }
+#endif
     const FilterRay fr = filter_ray(sg, o, d, a, ia, t_min);
     const int n_fwords = sg.n_fpairs >> 5;
     for (int fw0 = 0; fw0 < n_fwords; fw0 += kMaskWords) {

@@ -137,3 +137,13 @@ def bits_equal(a, b):
 def same_values(a, b):
     """Equality that treats NaN == NaN (any payload) and -0 == +0."""
     return np.array_equal(a, b, equal_nan=True)
+
+
+def same_bits_or_nan(a, b):
+    """Bitwise equality (signed zeros included) except that any NaN equals any NaN (payloads are not part of the contract)."""
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    assert a.dtype == b.dtype and a.shape == b.shape, (a.dtype, b.dtype, a.shape, b.shape)
+    if a.dtype.kind != "f":
+        return bool(np.array_equal(a, b))
+    iv = {4: np.uint32, 8: np.uint64}[a.dtype.itemsize]
+    return bool(np.all((a.view(iv) == b.view(iv)) | (np.isnan(a) & np.isnan(b))))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: render a workload with the RT_STAMPS build of the library (tools/libray_amd_stamps.so,
 built by hand with -DRT_STAMPS) and print the cycle share of each section of the render loop.
-    python tools/stamps.py [workload] [spp]"""
+    python tools/stamps.py [workload] [spp] [depth]"""
 import ctypes as C
 import os
 import sys
@@ -13,6 +13,8 @@ import bench  # noqa: E402
 
 wl = dict(bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "c3"])
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+if len(sys.argv) > 3:
+    wl["depth"] = int(sys.argv[3])
 ctx = api.Context(0, lib_path=os.path.join(ROOT, "tools", "libray_amd_stamps.so"))
 scene = scenes.get_scene(wl["scene"], **wl["kw"])
 ctx.upload_scene(scene)
@@ -32,7 +34,7 @@ names = ["assign+new sample", "exact group", "filter", "candidate walk", "rect+t
 batches = t[1]
 t[1] = 0
 tot = sum(t[:8])
-print(f"{wl['desc']} at {spp} spp: {ms:.2f} ms, {n_rays / ms / 1e3:.0f} Mrays/s (stamped build; read shares, not speed)")
+print(f"{wl['desc']} at {spp} spp, depth {wl['depth']}: {ms:.2f} ms, {n_rays / ms / 1e3:.0f} Mrays/s (stamped build; read shares, not speed)")
 scans = t[11]
 for n, v in zip(names, t[:8]):
     print(f"  {n:22s} {100.0 * v / tot:6.2f} %   {v / max(scans, 1):9.0f} cycles per wave-scan")
