@@ -219,6 +219,11 @@ __device__ __forceinline__ uint32_t flag_rects(const DevScene& sc, const FilterR
 }
 constexpr int kRectFlagMin = 16;   // fewer rects: the direct loop of scan_rects
 
+#ifdef RT_EXPERIMENT_TRI_STAGED
+#define RT_WORDS_ALIGN __align__(16)   // the staging rows are read as float4
+#else
+#define RT_WORDS_ALIGN
+#endif
 // Triangle (not in the reference; DESIGN.md "triangles"): Moeller-Trumbore, FP32, NaN = miss.
 RT_DEV bool tri_t(const Ray& r, const float* __restrict__ q, double t_min, double bt, int idx, int bi, double* t_out) {
     V3 v0 = v3(q[0], q[1], q[2]), e1 = v3(q[3], q[4], q[5]), e2 = v3(q[6], q[7], q[8]);
@@ -325,10 +330,19 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     if (tg.n_fpairs == 0) return;
     const FilterRay fr = filter_ray(tg, r.o, r.d, r.dl2, __builtin_amdgcn_rcpf(r.dl2), t_min);
     const int n_fwords = tg.n_fpairs >> 5;
-    for (int fw0 = 0; fw0 < n_fwords; fw0 += kMaskWords / 2) {
-        if (!chunk_needed(tg, fr, __double2float_ru(h.t), fw0 / (kMaskWords / 2))) continue;
-        const int nw = n_fwords - fw0 < kMaskWords / 2 ? n_fwords - fw0 : kMaskWords / 2;
+#ifdef RT_EXPERIMENT_TRI_STAGED
+    // the lanes that are here copy the filter data to LDS for each other (the loops below are wave-uniform: the set does not change)
+    const unsigned long long here = __ballot(true);
+    const int rank = int(__builtin_amdgcn_mbcnt_hi(uint32_t(here >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(here), 0u))), nact = __popcll(here);
+#endif
+    for (int fw0 = 0; fw0 < n_fwords; fw0 += kItemChunkWords) {
+        if (!chunk_needed(tg, fr, __double2float_ru(h.t), fw0 / kItemChunkWords)) continue;
+        const int nw = n_fwords - fw0 < kItemChunkWords ? n_fwords - fw0 : kItemChunkWords;
+#ifdef RT_EXPERIMENT_TRI_STAGED
+        const uint32_t summary = filter_words_staged(tg, fr, __double2float_ru(h.t), fw0, nw, words, rank, nact RT_STAMP_ARG);
+#else
         const uint32_t summary = filter_words<true>(tg, fr, __double2float_ru(h.t), fw0, nw, words RT_STAMP_ARG);
+#endif
         RT_STAMP(2);
         walk_flagged_items(summary, tg.n_ewords + fw0, words, visit RT_STAMP_ARG);
         RT_STAMP(3);
@@ -732,7 +746,7 @@ struct RenderArgs {
 // pixels, rayview.cpp:69-70) instead of the tiles of a row range.
 template <bool VERIFY, bool PIXELS = false, int RECTS = 0, int MEDIA = 0, int TRIS = 0>
 __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra) {
-    __shared__ uint32_t s_words[kMaskWords * kBlock];
+    __shared__ RT_WORDS_ALIGN uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int tiles_x = (ra.W + kTile - 1) / kTile;
@@ -889,7 +903,7 @@ __global__ void render_black_pixels_kernel(int n, int n_frame, const int* __rest
 
 __global__ __launch_bounds__(kBlock) void primary_kernel(DevScene sc, DevCamera cam, int W, int H, uint64_t seed,
                                                          int* __restrict__ prim_out, double* __restrict__ t_out) {
-    __shared__ uint32_t s_words[kMaskWords * kBlock];
+    __shared__ RT_WORDS_ALIGN uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
     const int tiles_x = (W + 15) / 16, tiles_y = (H + 15) / 16;
     for (int tile = blockIdx.x; tile < tiles_x * tiles_y; tile += gridDim.x) {
@@ -915,7 +929,7 @@ __global__ __launch_bounds__(kBlock) void hit_rays_kernel(DevScene sc, long long
                                                           int* __restrict__ prim_out, double* __restrict__ t_out,
                                                           float* __restrict__ p_out, float* __restrict__ n_out,
                                                           uint8_t* __restrict__ ff_out) {
-    __shared__ uint32_t s_words[kMaskWords * kBlock];
+    __shared__ RT_WORDS_ALIGN uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
     for (long long i = blockIdx.x * (long long)kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
         Ray ray = make_ray(v3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]), v3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]));
@@ -937,7 +951,7 @@ __global__ __launch_bounds__(kBlock) void hit_rays_kernel(DevScene sc, long long
 __global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene sc, long long n, const float* __restrict__ ro,
                                                             const float* __restrict__ rd, int depth, uint64_t seed, uint32_t flags,
                                                             float* __restrict__ rgb, float4* __restrict__ stack) {
-    __shared__ uint32_t s_words[kMaskWords * kBlock];
+    __shared__ RT_WORDS_ALIGN uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
     __shared__ float4 s_stack[kLdsLevels * kBlock];
     PathStack st; st.lds = s_stack + threadIdx.x; st.base = stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
@@ -1086,7 +1100,7 @@ void free_scene() {
 struct GroupBuild {
     FilterGroup fg{};
     std::vector<int> slot_item;
-    std::vector<float> fx, fy, fz, fk, bnd, wbnd, cbnd;
+    std::vector<float> fx, fy, fz, fk, fi, bnd, wbnd, cbnd;
 };
 // Order `order` (indices into a point set) into spatially compact runs of 16: median splits along the widest
 // axis, every part but the last a whole number of runs.
@@ -1505,7 +1519,15 @@ int rt_upload_scene(const RtScene* s) {
             r2k.push_back(q[15] * 1.0001f);
             ++i;
         }
-        build_group(bound, r2k, kMarginKTri, finite, kMaskWords / 2, tgb);
+        build_group(bound, r2k, kMarginKTri, finite, kItemChunkWords, tgb);
+#ifdef RT_EXPERIMENT_TRI_STAGED
+        tgb.fi.resize(tgb.fx.size() * 4);   // staged copy of the filter data: per pair x0 x1 y0 y1 z0 z1 k0 k1
+        for (size_t pr = 0; pr < tgb.fx.size() / 2; ++pr)
+            for (int e = 0; e < 2; ++e) {
+                tgb.fi[8 * pr + e] = tgb.fx[2 * pr + e]; tgb.fi[8 * pr + 2 + e] = tgb.fy[2 * pr + e];
+                tgb.fi[8 * pr + 4 + e] = tgb.fz[2 * pr + e]; tgb.fi[8 * pr + 6 + e] = tgb.fk[2 * pr + e];
+            }
+#endif
         const float nanf_ = std::numeric_limits<float>::quiet_NaN();
         std::vector<float> tri2(tgb.slot_item.size() * 2 * 16, nanf_);   // two triangle slots per item slot
         std::vector<int> prim2(tgb.slot_item.size() * 2, -1);
@@ -1693,6 +1715,10 @@ int rt_upload_scene(const RtScene* s) {
         upload(sgb.bnd, &sgb.fg.bnd) || upload(sgb.wbnd, &sgb.fg.wbnd) || upload(sgb.cbnd, &sgb.fg.cbnd) || upload(fq, &sgb.fg.fq)) return 1;
     if (upload(tgb.fx, &tgb.fg.fx) || upload(tgb.fy, &tgb.fg.fy) || upload(tgb.fz, &tgb.fg.fz) || upload(tgb.fk, &tgb.fg.fk) ||
         upload(tgb.bnd, &tgb.fg.bnd) || upload(tgb.wbnd, &tgb.fg.wbnd) || upload(tgb.cbnd, &tgb.fg.cbnd)) return 1;
+#ifdef RT_EXPERIMENT_TRI_STAGED
+    if (upload(tgb.fi, &tgb.fg.fi)) return 1;
+    sgb.fg.fi = nullptr;
+#endif
     tgb.fg.fq = nullptr;
 #ifdef RT_EXPERIMENT_SPHERE_BVH
     tgb.fg.sbvh = nullptr; tgb.fg.sbvh_extent = 0.0f;

@@ -33,6 +33,15 @@ typedef const f2 __attribute__((address_space(4)))* cf2p;
 
 constexpr int kMaskWords = 16;                 // flag words per lane and chunk (32 pairs each), kept in LDS
 constexpr int kScanBlock = 256;                // threads per block of every kernel that scans
+// Groups with one flag per ITEM (triangles): chunks of kItemChunkWords filter words, item 0's flags in the first kItemChunkWords
+// words of the lane's column, item 1's in the next.
+#ifdef RT_EXPERIMENT_TRI_STAGED
+// Experiment (tools/build_exp_tri_staged.sh): chunks of 6, and rows 12..15 of the wave's 64 columns (4 x 256 B) are
+// its staging rows for the filter data of one word's 4 batches (filter_words_staged)
+constexpr int kItemChunkWords = 6, kStageWord = 12;
+#else
+constexpr int kItemChunkWords = 8;
+#endif
 // Filter margin factor: M = kMarginK * a * (S^2 + So^2 + r2max) with S = |o'| + cmax, So = |o - g| + cmax.
 // 96 * 2^-24, against a derived bound of < 64 * 2^-24.
 constexpr float kMarginK = 96.0f * 5.9604644775390625e-08f;
@@ -50,12 +59,15 @@ struct FilterGroup {
     const float* __restrict__ fy;
     const float* __restrict__ fz;
     const float* __restrict__ fk;    // [2 n_fpairs] |centre - g|^2 - r^2                   (pads: 3e38)
+#ifdef RT_EXPERIMENT_TRI_STAGED
+    const float* __restrict__ fi;    // item groups only: the same four, interleaved per pair (x0 x1 y0 y1 z0 z1 k0 k1): 256 B per batch
+#endif
     const float4* __restrict__ fq;   // spheres only: [2 * all pairs] per pair (cx0,cx1,cy0,cy1), (cz0,cz1,r2_0,r2_1); pads NaN
     const float* __restrict__ bnd;   // [24 per filter word] boxes of the word's 4 batches, relative to g, item radii included:
                                      // lo x0..x3, lo y0..y3, lo z0..z3, hi x0..x3, hi y0..y3, hi z0..z3
     const float* __restrict__ wbnd;  // [12 per pair of filter words] box around each word's batches: lo x (word 0, word 1), lo y, lo z, hi x, hi y, hi z
     const float* __restrict__ cbnd;  // [12 per pair of chunks] the same around each chunk of chunk_words filter words
-    int chunk_words;                 // filter words per chunk: kMaskWords (one flag per pair) or kMaskWords / 2 (one per item)
+    int chunk_words;                 // filter words per chunk: kMaskWords (one flag per pair) or kItemChunkWords (one per item)
     int n_fbatches;                  // batches that hold items (the rest of the last word is padding)
     float gx, gy, gz;                // reference point of the filter group
     float cmax, r2max;               // max |centre - g| (rounded up), max r^2 over the filter group
@@ -296,6 +308,15 @@ __device__ __forceinline__ f2 pk_fma_cc_v(f2 c, f2 x, f2 a) {
     else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(c), "v"(x), "v"(a));
     return r;
 }
+#ifdef RT_EXPERIMENT_TRI_STAGED
+template <int SC>
+__device__ __forceinline__ f2 pk_fma_cv_v(f2 c, f2 x, f2 a) {
+    f2 r;
+    if (SC == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(c), "v"(x), "v"(a));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(c), "v"(x), "v"(a));
+    return r;
+}
+#endif
 __device__ __forceinline__ void box_pair_v(const FilterRay& fr, float t_hi, f2 LX, f2 LY, f2 LZ, f2 HX, f2 HY, f2 HZ, bool& n0, bool& n1, float& e0,
                                            float& e1) {
     const f2 x1 = pk_fma_cc_v<0, 0>(fr.I01, LX, fr.CX), x2 = pk_fma_cc_v<0, 1>(fr.I01, HX, fr.CX);
@@ -328,7 +349,7 @@ __device__ __forceinline__ bool chunk_needed(const FilterGroup& fg, const Filter
 // 31 - p), words to this thread's LDS column; returns the mask of non-empty words. t_hi: upper bound of the
 // best t so far (boxes wholly beyond it are not needed).
 // ITEMS: one flag per ITEM instead (for kinds whose exact test is expensive per item: triangles): item 0's
-// flags of word wi at words[wi], item 1's at words[wi + kMaskWords / 2]; nw <= kMaskWords / 2.
+// flags of word wi at words[wi], item 1's at words[wi + kItemChunkWords]; nw <= kItemChunkWords.
 template <bool ITEMS = false>
 __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const FilterRay& fr, float t_hi, int fw0, int nw, uint32_t* words RT_STAMP_PARAM) {
     cf2p fx = RT_CONST_F2(fg.fx), fy = RT_CONST_F2(fg.fy), fz = RT_CONST_F2(fg.fz), fk = RT_CONST_F2(fg.fk);
@@ -387,11 +408,117 @@ __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const Fi
         }
         const uint32_t flagged = ITEMS ? ~(m & m1) : ~m;
         words[wi * kScanBlock] = ~m;
-        if (ITEMS) words[(wi + kMaskWords / 2) * kScanBlock] = ~m1;
+        if (ITEMS) words[(wi + kItemChunkWords) * kScanBlock] = ~m1;
         summary |= (flagged != 0u ? 1u : 0u) << wi;
     }
     return summary;
 }
+
+#ifdef RT_EXPERIMENT_TRI_STAGED
+// filter_words<true> with the filter data of a word staged through LDS (BASELINE north_star, config 4: "primitive batches staged
+// through LDS") instead of read through the scalar cache, which a triangle group of thousands of items does not fit (50 % hits
+// on the 9.8k-triangle frame, profiles/r2_scalar_cache.txt): the wave's active lanes copy the 256 B of every batch that some lane
+// needs into the wave's staging rows with one coalesced load each, and every lane then reads each pair's 32 B back with two
+// broadcast reads. LDS operations of one wave complete in order, so the wave needs no barrier, only the compiler must keep the order.
+// rank / nact: this lane's rank among the active lanes of the wave and their number (all 64 lanes in the steady state of
+// render_kernel: one trip of the copy loop).
+// MEASURED SLOWER than the scalar-cache path (9.8k triangles, 1080p, 64 spp: 86.9 ms copy-then-filter, 90.3 ms with the next word's
+// loads in flight as below, against 82.5 ms for the scalar path with the same chunks of 6 and 78.3 ms with the product's chunks of 8;
+// profiles/r2_exp_tri_staged.txt): an experiment build only.
+__device__ __forceinline__ uint32_t filter_words_staged(const FilterGroup& fg, const FilterRay& fr, float t_hi, int fw0, int nw, uint32_t* words, int rank,
+                                                        int nact RT_STAMP_PARAM) {
+    uint32_t* stage = words - (threadIdx.x & 63) + kStageWord * kScanBlock;   // wave-uniform: batch bb of the word at stage + bb * kScanBlock
+    const uint32_t* __restrict__ fi = reinterpret_cast<const uint32_t*>(fg.fi);
+    uint32_t summary = 0;
+    uint32_t wact = 0;
+    for (int q = 0; 2 * q < nw; ++q) {
+        cf2p wb = RT_CONST_F2(fg.wbnd) + (fw0 / 2 + q) * 6;
+        bool n0, n1;
+        box_pair(fr, t_hi, wb[0], wb[1], wb[2], wb[3], wb[4], wb[5], n0, n1);
+        wact |= (__ballot(n0) != 0ull ? 1u : 0u) << (2 * q);
+        wact |= (__ballot(n1) != 0ull && 2 * q + 1 < nw ? 1u : 0u) << (2 * q + 1);
+    }
+    // level 0, batches of word wi: which this lane needs (nd), which any lane needs (returned)
+    auto batch_boxes = [&](int wi, bool (&nd)[4]) {
+        const int fw = fw0 + wi;
+        cf2p bn = RT_CONST_F2(fg.bnd) + fw * 12;
+        box_pair(fr, t_hi, bn[0], bn[2], bn[4], bn[6], bn[8], bn[10], nd[0], nd[1]);
+        box_pair(fr, t_hi, bn[1], bn[3], bn[5], bn[7], bn[9], bn[11], nd[2], nd[3]);
+        const int real = fg.n_fbatches - fw * 4;
+        uint32_t act = 0;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) act |= (__ballot(nd[bb]) != 0ull && bb < real ? 1u : 0u) << bb;
+        RT_BATCHES(act);
+        return act;
+    };
+    // software pipeline over the words that some lane needs: while word wi is filtered out of LDS, the loads of the next
+    // needed word's batches are in flight (v); a wave that is not full copies without the pipeline (each lane several dwords)
+    const bool full = nact == 64;
+    uint32_t v[4] = {0u, 0u, 0u, 0u};
+    auto issue = [&](int wi, uint32_t act) {
+        const uint32_t* __restrict__ src = fi + size_t(fw0 + wi) * 256 + rank;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) if (act >> bb & 1u) v[bb] = src[bb * 64];
+    };
+    int wi = wact != 0u ? __builtin_ctz(wact) : nw;
+    bool nd[4] = {false, false, false, false};
+    uint32_t act = 0;
+    if (wi < nw) { act = batch_boxes(wi, nd); if (full) issue(wi, act); }
+    while (wi < nw) {
+        const uint32_t rest = wact & ~((2u << wi) - 1u);
+        const int wj = rest != 0u ? __builtin_ctz(rest) : nw;
+        bool nd2[4] = {false, false, false, false};
+        uint32_t act2 = 0;
+        if (wj < nw) act2 = batch_boxes(wj, nd2);
+        uint32_t m = 0xffffffffu, m1 = 0xffffffffu;            // bit set: item 0 / item 1 of the pair NOT flagged
+        asm volatile("" ::: "memory");                         // the previous word's reads stay before these writes
+        if (full) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) if (act >> bb & 1u) stage[bb * kScanBlock + rank] = v[bb];
+        } else {
+            const uint32_t* __restrict__ src = fi + size_t(fw0 + wi) * 256;
+            for (int dw = rank; dw < 64; dw += nact) {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) if (act >> bb & 1u) stage[bb * kScanBlock + dw] = src[bb * 64 + dw];
+            }
+        }
+        asm volatile("" ::: "memory");                         // and the reads below after them
+        if (full && wj < nw) issue(wj, act2);
+        if (act != 0u) {
+            m = 0; m1 = 0;
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                if ((act >> bb & 1u) == 0u) { m = (m << 8) | 0xffu; m1 = (m1 << 8) | 0xffu; continue; }
+                const float4* __restrict__ row = reinterpret_cast<const float4*>(stage + bb * kScanBlock);
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float4 A = row[2 * jj], B = row[2 * jj + 1];
+                    const f2 X = {A.x, A.y}, Y = {A.z, A.w}, Z = {B.x, B.y}, K = {B.z, B.w};
+                    f2 bq = pk_fma_cc_v<0, 1>(fr.D01, X, fr.D2O);
+                    bq = pk_fma_cv_v<1>(fr.D01, Y, bq);
+                    bq = pk_fma_cv_v<0>(fr.D2O, Z, bq);
+                    f2 Q = pk_fma_cc_v<0, 1>(fr.NAM, K, fr.NAM);
+                    Q = pk_fma_cv_v<0>(fr.W01, X, Q);
+                    Q = pk_fma_cv_v<1>(fr.W01, Y, Q);
+                    Q = pk_fma_cv_v<0>(fr.W2, Z, Q);
+                    const f2 T = __builtin_elementwise_fma(bq, bq, Q);   // >= 0 (sign bit clear): flagged
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x), 31);
+                    m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(T.y), 31);
+                }
+                m |= nd[bb] ? 0u : 0xffu;                          // this lane does not need the batch
+                m1 |= nd[bb] ? 0u : 0xffu;
+            }
+        }
+        words[wi * kScanBlock] = ~m;
+        words[(wi + kItemChunkWords) * kScanBlock] = ~m1;
+        summary |= (~(m & m1) != 0u ? 1u : 0u) << wi;
+        wi = wj; act = act2;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) nd[bb] = nd2[bb];
+    }
+    return summary;
+}
+#endif
 
 // Level 2 driver: each lane walks its own flagged pairs of the chunk and calls visit(pair).
 // w0: word index of the chunk in pair space.
@@ -423,7 +550,7 @@ __device__ __forceinline__ void walk_flagged_items(uint32_t summary, int w0, con
             const int wi = __builtin_ctz(summary);
             summary &= summary - 1u;
             cur0 = words[wi * kScanBlock];
-            cur1 = words[(wi + kMaskWords / 2) * kScanBlock];
+            cur1 = words[(wi + kItemChunkWords) * kScanBlock];
             wbase = (w0 + wi) * 32;
         }
         const bool second = cur0 == 0u;                    // item 0 flags of the word first, then item 1
