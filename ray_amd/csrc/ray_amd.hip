@@ -1175,6 +1175,12 @@ void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k
         out.slot_item.push_back(-1);
     }
     fg.n_fpairs = int(out.fx.size() / 2);
+    out.fi.resize(out.fx.size() * 4);   // the device's copy: interleaved per pair
+    for (size_t pr = 0; pr < out.fx.size() / 2; ++pr)
+        for (int e = 0; e < 2; ++e) {
+            out.fi[8 * pr + e] = out.fx[2 * pr + e]; out.fi[8 * pr + 2 + e] = out.fy[2 * pr + e];
+            out.fi[8 * pr + 4 + e] = out.fz[2 * pr + e]; out.fi[8 * pr + 6 + e] = out.fk[2 * pr + e];
+        }
     // box of every batch around its items' spheres (radius: the one the filter uses), relative to g, rounded outwards
     const int n_fwords = fg.n_fpairs / 32, n_items = int(order.size());
     fg.n_fbatches = (n_items + 15) / 16;
@@ -1520,14 +1526,7 @@ int rt_upload_scene(const RtScene* s) {
             ++i;
         }
         build_group(bound, r2k, kMarginKTri, finite, kItemChunkWords, tgb);
-#ifdef RT_EXPERIMENT_TRI_STAGED
-        tgb.fi.resize(tgb.fx.size() * 4);   // staged copy of the filter data: per pair x0 x1 y0 y1 z0 z1 k0 k1
-        for (size_t pr = 0; pr < tgb.fx.size() / 2; ++pr)
-            for (int e = 0; e < 2; ++e) {
-                tgb.fi[8 * pr + e] = tgb.fx[2 * pr + e]; tgb.fi[8 * pr + 2 + e] = tgb.fy[2 * pr + e];
-                tgb.fi[8 * pr + 4 + e] = tgb.fz[2 * pr + e]; tgb.fi[8 * pr + 6 + e] = tgb.fk[2 * pr + e];
-            }
-#endif
+
         const float nanf_ = std::numeric_limits<float>::quiet_NaN();
         std::vector<float> tri2(tgb.slot_item.size() * 2 * 16, nanf_);   // two triangle slots per item slot
         std::vector<int> prim2(tgb.slot_item.size() * 2, -1);
@@ -1711,14 +1710,10 @@ int rt_upload_scene(const RtScene* s) {
     for (int i = 0; i < s->n_mats; ++i) minv[i] = 1.0 / mir[i];
     if (upload(mk, &ds.mat_kind) || upload(mrgb, &ds.mat_rgb) || upload(mf, &ds.mat_fuzz) || upload(mir, &ds.mat_ir) ||
         upload(minv, &ds.mat_inv_ir)) return 1;
-    if (upload(sgb.fx, &sgb.fg.fx) || upload(sgb.fy, &sgb.fg.fy) || upload(sgb.fz, &sgb.fg.fz) || upload(sgb.fk, &sgb.fg.fk) ||
+    if (upload(sgb.fi, &sgb.fg.fi) ||
         upload(sgb.bnd, &sgb.fg.bnd) || upload(sgb.wbnd, &sgb.fg.wbnd) || upload(sgb.cbnd, &sgb.fg.cbnd) || upload(fq, &sgb.fg.fq)) return 1;
-    if (upload(tgb.fx, &tgb.fg.fx) || upload(tgb.fy, &tgb.fg.fy) || upload(tgb.fz, &tgb.fg.fz) || upload(tgb.fk, &tgb.fg.fk) ||
+    if (upload(tgb.fi, &tgb.fg.fi) ||
         upload(tgb.bnd, &tgb.fg.bnd) || upload(tgb.wbnd, &tgb.fg.wbnd) || upload(tgb.cbnd, &tgb.fg.cbnd)) return 1;
-#ifdef RT_EXPERIMENT_TRI_STAGED
-    if (upload(tgb.fi, &tgb.fg.fi)) return 1;
-    sgb.fg.fi = nullptr;
-#endif
     tgb.fg.fq = nullptr;
 #ifdef RT_EXPERIMENT_SPHERE_BVH
     tgb.fg.sbvh = nullptr; tgb.fg.sbvh_extent = 0.0f;

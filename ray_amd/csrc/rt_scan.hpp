@@ -55,13 +55,8 @@ constexpr float kMaxCoord = 1.0e6f, kMinA = 1.0e-12f, kMaxA = 3.0e12f;
 struct FilterGroup {
     int n_epairs, n_ewords;
     int n_fpairs;
-    const float* __restrict__ fx;    // [2 n_fpairs] centre - g, filter group only          (pads: 0)
-    const float* __restrict__ fy;
-    const float* __restrict__ fz;
-    const float* __restrict__ fk;    // [2 n_fpairs] |centre - g|^2 - r^2                   (pads: 3e38)
-#ifdef RT_EXPERIMENT_TRI_STAGED
-    const float* __restrict__ fi;    // item groups only: the same four, interleaved per pair (x0 x1 y0 y1 z0 z1 k0 k1): 256 B per batch
-#endif
+    const float* __restrict__ fi;    // [8 n_fpairs] filter group only, per pair x0 x1 y0 y1 z0 z1 k0 k1 (256 B per batch, one base pointer):
+                                     // x, y, z = centre - g (pads: 0), k = |centre - g|^2 - r^2 (pads: 3e38)
     const float4* __restrict__ fq;   // spheres only: [2 * all pairs] per pair (cx0,cx1,cy0,cy1), (cz0,cz1,r2_0,r2_1); pads NaN
     const float* __restrict__ bnd;   // [24 per filter word] boxes of the word's 4 batches, relative to g, item radii included:
                                      // lo x0..x3, lo y0..y3, lo z0..z3, hi x0..x3, hi y0..y3, hi z0..z3
@@ -352,7 +347,7 @@ __device__ __forceinline__ bool chunk_needed(const FilterGroup& fg, const Filter
 // flags of word wi at words[wi], item 1's at words[wi + kItemChunkWords]; nw <= kItemChunkWords.
 template <bool ITEMS = false>
 __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const FilterRay& fr, float t_hi, int fw0, int nw, uint32_t* words RT_STAMP_PARAM) {
-    cf2p fx = RT_CONST_F2(fg.fx), fy = RT_CONST_F2(fg.fy), fz = RT_CONST_F2(fg.fz), fk = RT_CONST_F2(fg.fk);
+    cf2p fi = RT_CONST_F2(fg.fi);
     uint32_t summary = 0;
     // level 0, words: the box around each word's 4 batches, two words per packed operation (fw0 is even)
     uint32_t wact = 0;                                     // wave-uniform: words that some lane needs
@@ -386,7 +381,7 @@ __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const Fi
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
                     const int j = batch * 8 + jj;
-                    const f2 X = fx[j], Y = fy[j], Z = fz[j], K = fk[j];
+                    const f2 X = fi[4 * j], Y = fi[4 * j + 1], Z = fi[4 * j + 2], K = fi[4 * j + 3];
                     f2 bq = pk_fma_cc<0, 1>(fr.D01, X, fr.D2O);
                     bq = pk_fma_cv<1>(fr.D01, Y, bq);
                     bq = pk_fma_cv<0>(fr.D2O, Z, bq);
