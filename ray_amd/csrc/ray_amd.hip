@@ -398,6 +398,16 @@ __device__ __forceinline__ void scan_triangles_bvh(const DevScene& sc, const Ray
     }
 }
 
+template <class T>
+__device__ __forceinline__ T load_kernarg(size_t offset) {
+    const char __attribute__((address_space(4)))* p = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    T v;   // copied through a pointer to T: the copy is known to be aligned, which scalar loads need
+    __builtin_memcpy(&v, (const T __attribute__((address_space(4)))*)(p + offset), sizeof(T));
+    return v;
+}
+
+
 // Fast scan: spheres through rt_scan.hpp (filter + exact), then rects and triangles. Lanes whose ray
 // is outside the fast range (non-finite, huge, zero direction), a scene that is, or a NaN t from a
 // rect, fall back to the list-order scan, which is the reference loop itself.
@@ -410,7 +420,9 @@ __device__ __forceinline__ void scan_triangles_bvh(const DevScene& sc, const Ray
 // the medium's code merely being present costs the other workloads registers (16 VGPRs spilled to scratch).
 // TRIS: 0 = the triangle group through the flat box / filter / walk levels, 1 = through the BVH (the launcher picks it
 // when rt_upload_scene built one), 2 = decide at run time.
-template <int RECTS = 2, int MEDIA = 2, int TRIS = 2>
+// KARG: the caller is render_kernel, whose first argument is the scene: every group's fields are read from the kernarg segment
+// where its scan starts (load_kernarg), so that they occupy scalar registers during that scan only.
+template <int RECTS = 2, int MEDIA = 2, int TRIS = 2, bool KARG = false>
 __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, double t_min, double t_max, Rng& g, uint32_t* words RT_STAMP_PARAM) {
     Hit h; h.t = t_max; h.prim = -1;
     if (MEDIA == 1) return closest_hit_listorder<true>(sc, r, t_min, t_max, g);
@@ -418,7 +430,10 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
     if (ok) {
         HitState hs;
         hit_state_init(hs, t_max);
-        scan_spheres(sc.sg, sc.sph_prim, r.o, r.d, r.dl2, t_min, t_max, hs, words RT_STAMP_ARG);
+        {
+            const FilterGroup sg_here = KARG ? load_kernarg<FilterGroup>(offsetof(DevScene, sg)) : sc.sg;
+            scan_spheres(sg_here, sc.sph_prim, r.o, r.d, r.dl2, t_min, t_max, hs, words RT_STAMP_ARG);
+        }
         h.t = hs.bt; h.prim = hs.idx;
         bool saw_nan = false;
         if (RECTS == 1 || (RECTS == 2 && sc.n_rect >= kRectFlagMin)) {
@@ -455,9 +470,10 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
             scan_rects<1>(sc.rect, sc.rect_f, sc.rect_prim, sc.n_rect_xy, sc.n_rect_xy + sc.n_rect_xz, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
             scan_rects<2>(sc.rect, sc.rect_f, sc.rect_prim, sc.n_rect_xy + sc.n_rect_xz, sc.n_rect, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
         }
-        if (!saw_nan) {
-            if (TRIS == 1 || (TRIS == 2 && sc.tbvh != nullptr)) scan_triangles_bvh(sc, r, t_min, h, words);
-            else scan_triangles(sc, r, t_min, h, words RT_STAMP_ARG);
+        if (!saw_nan && (sc.tg.n_epairs | sc.tg.n_fpairs) != 0) {
+            const DevScene sc_tri = KARG ? load_kernarg<DevScene>(0) : sc;
+            if (TRIS == 1 || (TRIS == 2 && sc.tbvh != nullptr)) scan_triangles_bvh(sc_tri, r, t_min, h, words);
+            else scan_triangles(sc_tri, r, t_min, h, words RT_STAMP_ARG);
         }
         ok = !saw_nan;
     }
@@ -736,6 +752,18 @@ struct RenderArgs {
     int n_pixels;
 };
 
+// The render kernel's arguments as they lie in the kernarg segment. Values that one section of the main loop needs are read from
+// there (scalar loads through the constant address space) where they are used, behind a pointer the compiler cannot see through:
+// left to itself it loads every argument once at kernel entry and then keeps ~280 scalars alive across the whole loop by spilling
+// them to VGPR lanes, and every use costs a v_readlane - a VALU slot in a kernel that is bound by VALU issue; the scalar memory
+// pipe is idle.
+struct RenderKernArgs {
+    DevScene sc;
+    DevCamera cam;
+    RenderArgs ra;
+};
+static_assert(offsetof(RenderKernArgs, sc) == 0, "closest_hit<..., KARG> reads the scene at offset 0 of the kernarg segment");
+
 // Persistent waves with path regeneration. Every lane owns one pixel at a time and walks its samples
 // in order (the reference sums a pixel's samples in order, rayview.cpp:79-84); each trip of the main
 // loop does exactly ONE closest-hit scan for every lane that has a pixel, whatever bounce its path is
@@ -745,16 +773,12 @@ struct RenderArgs {
 // PIXELS: the work items are the entries of a caller-supplied pixel list (RayView::renderOneRay's random
 // pixels, rayview.cpp:69-70) instead of the tiles of a row range.
 template <bool VERIFY, bool PIXELS = false, int RECTS = 0, int MEDIA = 0, int TRIS = 0>
-__global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra) {
+__global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra_entry) {
     __shared__ RT_WORDS_ALIGN uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int tiles_x = (ra.W + kTile - 1) / kTile;
-    const int total = PIXELS ? ra.n_pixels : tiles_x * ra.tiles_y * 64;
     __shared__ float4 s_stack[kLdsLevels * kBlock];
-    PathStack st; st.lds = s_stack + threadIdx.x; st.base = ra.stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
-    const bool normals = (ra.flags & RT_RENDER_NORMALS) != 0;
-    const int spp_end = ra.spp_begin + ra.spp_count;
+    PathStack st; st.lds = s_stack + threadIdx.x; st.base = ra_entry.stack; st.stride = gridDim.x * kBlock; st.tid = blockIdx.x * kBlock + threadIdx.x;
     const Recip64 rpi = recip64(kPi);
 
     bool have = false, path = false;
@@ -775,6 +799,9 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
         for (;;) {
             const unsigned long long need = __ballot(!have);
             if (need == 0ull) break;
+            const RenderArgs ra = load_kernarg<RenderArgs>(offsetof(RenderKernArgs, ra));   // (every section reads its arguments where it uses them)
+            const int tiles_x = (ra.W + kTile - 1) / kTile;
+            const int total = PIXELS ? ra.n_pixels : tiles_x * ra.tiles_y * 64;
             if (q_cur >= q_end) {
                 if (exhausted) break;
                 int base = 0;
@@ -812,24 +839,31 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
         if (__ballot(have) == 0ull) break;
         // ---- start the next sample of the lane's pixel (rayview.cpp:80-83) ----------------------------
         if (have && !path) {
+            const RenderArgs ra = load_kernarg<RenderArgs>(offsetof(RenderKernArgs, ra));
             g.key(ra.seed, pix, uint32_t(s));
             float u = (float(x) + g.u01()) / float(ra.W);
             float v = (float(y) + g.u01()) / float(ra.H);
-            ray = get_ray(cam, g, u, v);
+            const DevCamera cam_here = load_kernarg<DevCamera>(offsetof(RenderKernArgs, cam));
+            ray = get_ray(cam_here, g, u, v);
             level = 0; depth_left = ra.depth; path = true;
         }
         RT_STAMP(0);
         RT_COUNT(3);
         // ---- one closest-hit scan per lane, then one bounce ------------------------------------------------
+        const DevScene sc_scan = load_kernarg<DevScene>(offsetof(RenderKernArgs, sc));    // the groups' arrays and constants (wave-uniform code: scalars)
         if (path) {
+            const RenderArgs ra = load_kernarg<RenderArgs>(offsetof(RenderKernArgs, ra));
+            const bool normals = (ra.flags & RT_RENDER_NORMALS) != 0;
+            const int spp_end = ra.spp_begin + ra.spp_count;
             ++n_rays;
-            Hit h = closest_hit<RECTS, MEDIA, TRIS>(sc, ray, double(0.001f), kInf, g, words RT_STAMP_ARG);   // calc.cpp:99
+            Hit h = closest_hit<RECTS, MEDIA, TRIS, true>(sc_scan, ray, double(0.001f), kInf, g, words RT_STAMP_ARG);   // calc.cpp:99
             if (VERIFY) {   // scenes with a constant_medium (which draws inside the scan) are rejected for VERIFY by the host
                 Hit h2 = closest_hit_listorder<false>(sc, ray, double(0.001f), kInf, g);
                 if (h2.prim != h.prim || __double_as_longlong(h2.t) != __double_as_longlong(h.t)) atomicAdd(ra.mismatches, 1ull);
             }
             V3 L;
-            bool done = shade_bounce(sc, ray, h, g, normals, st, level, rpi, L);
+            const DevScene sc_shade = load_kernarg<DevScene>(offsetof(RenderKernArgs, sc));   // materials, lights, per-primitive records
+            bool done = shade_bounce(sc_shade, ray, h, g, normals, st, level, rpi, L);
             if (!done) {
                 ++level; --depth_left;
                 if (depth_left <= 0) { L = v3(0.0f, 0.0f, 0.0f); done = true; }   // calc.cpp:96-97
@@ -859,15 +893,15 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
         }
     }
 #ifdef RT_STAMPS
-    if (ra.stamps) {
-        for (int k = 0; k < 8; ++k) if (lane == 0) atomicAdd(ra.stamps + k, stp.t[k]);
-        for (int k = 0; k < 4; ++k) atomicAdd(ra.stamps + 8 + k, (unsigned long long)stp.cnt[k]);
+    if (ra_entry.stamps) {
+        for (int k = 0; k < 8; ++k) if (lane == 0) atomicAdd(ra_entry.stamps + k, stp.t[k]);
+        for (int k = 0; k < 4; ++k) atomicAdd(ra_entry.stamps + 8 + k, (unsigned long long)stp.cnt[k]);
     }
 #endif
-    if (ra.rays_out) {
+    if (ra_entry.rays_out) {
         unsigned long long v = n_rays;   // per-wave sum, one atomic per wave
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0 && v) atomicAdd(ra.rays_out, v);
+        if (lane == 0 && v) atomicAdd(ra_entry.rays_out, v);
     }
 }
 

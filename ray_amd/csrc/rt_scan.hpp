@@ -374,14 +374,19 @@ __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const Fi
         uint32_t m = 0xffffffffu, m1 = 0xffffffffu;            // bit set: pair (ITEMS: item 0, item 1) NOT flagged
         if (act != 0u) {
             m = 0; m1 = 0;
+            // the word's 1 KB of filter data: one SGPR pair for its 4 batches (left to itself the compiler re-derives the address
+            // per batch from a spilled 8-register tuple: 8 v_readlane per batch)
+            cf2p fiw = fi + fw * 128;
+#ifndef RT_NO_FIW_ASM
+            asm volatile("" : "+s"(fiw));
+#endif
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) {
                 if ((act >> bb & 1u) == 0u) { m = (m << 8) | 0xffu; if (ITEMS) m1 = (m1 << 8) | 0xffu; continue; }
-                const int batch = fw * 4 + bb;
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
-                    const int j = batch * 8 + jj;
-                    const f2 X = fi[4 * j], Y = fi[4 * j + 1], Z = fi[4 * j + 2], K = fi[4 * j + 3];
+                    const int j = bb * 8 + jj;
+                    const f2 X = fiw[4 * j], Y = fiw[4 * j + 1], Z = fiw[4 * j + 2], K = fiw[4 * j + 3];
                     f2 bq = pk_fma_cc<0, 1>(fr.D01, X, fr.D2O);
                     bq = pk_fma_cv<1>(fr.D01, Y, bq);
                     bq = pk_fma_cv<0>(fr.D2O, Z, bq);
