@@ -436,39 +436,42 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
         }
         h.t = hs.bt; h.prim = hs.idx;
         bool saw_nan = false;
-        if (RECTS == 1 || (RECTS == 2 && sc.n_rect >= kRectFlagMin)) {
+        if (sc.n_rect > 0) {
+        const DevScene scr = KARG ? load_kernarg<DevScene>(0) : sc;   // the rects' arrays, read only by scenes that have rects
+        if (RECTS == 1 || (RECTS == 2 && scr.n_rect >= kRectFlagMin)) {
             if (r.d.x == 0.0f || r.d.y == 0.0f || r.d.z == 0.0f) saw_nan = true;   // axis-parallel: the list-order loop
             FilterRay br;
             const float omax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(r.o.x), __builtin_fabsf(r.o.y)), __builtin_fabsf(r.o.z));
-            set_box_ray(br, r.o, r.d, r.dl2, 2.0e-5f * (omax + sc.rect_extent) + 1.0e-30f, t_min);
-            for (int c0 = 0; c0 < sc.n_rect && !saw_nan; c0 += 32 * kMaskWords) {
-                const int c1 = c0 + 32 * kMaskWords < sc.n_rect ? c0 + 32 * kMaskWords : sc.n_rect;
-                const uint32_t summary = flag_rects(sc, br, __double2float_ru(h.t), c0, c1, words);
+            set_box_ray(br, r.o, r.d, r.dl2, 2.0e-5f * (omax + scr.rect_extent) + 1.0e-30f, t_min);
+            for (int c0 = 0; c0 < scr.n_rect && !saw_nan; c0 += 32 * kMaskWords) {
+                const int c1 = c0 + 32 * kMaskWords < scr.n_rect ? c0 + 32 * kMaskWords : scr.n_rect;
+                const uint32_t summary = flag_rects(scr, br, __double2float_ru(h.t), c0, c1, words);
                 RT_STAMP(4);
                 walk_flagged(summary, c0 >> 5, words, [&](int j) {
                     // the ray's components along the rect's normal and in its plane, picked with bit masks: a select
                     // chain over ray components is turned into an indexed load from a scratch copy of the ray
-                    const int axis = sc.rect_axis[j];
+                    const int axis = scr.rect_axis[j];
                     uint32_t mxy = axis == 0 ? 0xffffffffu : 0u, mxz = axis <= 1 ? 0xffffffffu : 0u;
                     asm("" : "+v"(mxy), "+v"(mxz));
                     auto pick = [](uint32_t m, float a, float b) { return __uint_as_float((__float_as_uint(a) & m) | (__float_as_uint(b) & ~m)); };
                     const float ok = pick(mxy, r.o.z, pick(mxz, r.o.y, r.o.x)), dk = pick(mxy, r.d.z, pick(mxz, r.d.y, r.d.x));
                     const float oa = pick(mxz, r.o.x, r.o.y), da = pick(mxz, r.d.x, r.d.y);
                     const float ob = pick(mxy, r.o.y, r.o.z), db = pick(mxy, r.d.y, r.d.z);
-                    const double* q = sc.rect + 5 * j;
-                    const int idx = sc.rect_prim[j];
+                    const double* q = scr.rect + 5 * j;
+                    const int idx = scr.rect_prim[j];
                     double t;
                     if (rect_core(ok, dk, oa, da, ob, db, q[0], q[1], q[2], q[3], q[4], t_min, h.t, idx, h.prim, &t)) {
                         if (t != t) saw_nan = true; else { h.t = t; h.prim = idx; }
                     }
                 } RT_STAMP_ARG);
             }
-        } else if (RECTS != 1 && sc.n_rect > 0) {
+        } else if (RECTS != 1 && scr.n_rect > 0) {
             const float tminf = __double2float_rd(t_min);
             float btf = __double2float_ru(h.t);
-            scan_rects<0>(sc.rect, sc.rect_f, sc.rect_prim, 0, sc.n_rect_xy, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
-            scan_rects<1>(sc.rect, sc.rect_f, sc.rect_prim, sc.n_rect_xy, sc.n_rect_xy + sc.n_rect_xz, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
-            scan_rects<2>(sc.rect, sc.rect_f, sc.rect_prim, sc.n_rect_xy + sc.n_rect_xz, sc.n_rect, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
+            scan_rects<0>(scr.rect, scr.rect_f, scr.rect_prim, 0, scr.n_rect_xy, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
+            scan_rects<1>(scr.rect, scr.rect_f, scr.rect_prim, scr.n_rect_xy, scr.n_rect_xy + scr.n_rect_xz, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
+            scan_rects<2>(scr.rect, scr.rect_f, scr.rect_prim, scr.n_rect_xy + scr.n_rect_xz, scr.n_rect, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
+        }
         }
         if (!saw_nan && (sc.tg.n_epairs | sc.tg.n_fpairs) != 0) {
             const DevScene sc_tri = KARG ? load_kernarg<DevScene>(0) : sc;

@@ -37,8 +37,23 @@ __global__ __launch_bounds__(256) void k(float* out, float seed) {
             asm volatile("v_alignbit_b32 %0, %0, %8, 31\n v_alignbit_b32 %1, %1, %8, 31\n v_alignbit_b32 %2, %2, %8, 31\n v_alignbit_b32 %3, %3, %8, 31\n"
                          "v_alignbit_b32 %4, %4, %8, 31\n v_alignbit_b32 %5, %5, %8, 31\n v_alignbit_b32 %6, %6, %8, 31\n v_alignbit_b32 %7, %7, %8, 31\n"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));
+        } else if (MODE >= 17) {   // integer ops of the counter RNG (round 2)
+            uint32_t *u0 = reinterpret_cast<uint32_t*>(&a0), *u1 = reinterpret_cast<uint32_t*>(&a1), *u2 = reinterpret_cast<uint32_t*>(&a2), *u3 = reinterpret_cast<uint32_t*>(&a3);
+            const uint32_t c = 747796405u;
+            if (MODE == 17) asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4\n"
+                                         : "+v"(*u0), "+v"(*u1), "+v"(*u2), "+v"(*u3) : "v"(c));
+            if (MODE == 18) asm volatile("v_mad_u32_u24 %0, %0, %4, %4\n v_mad_u32_u24 %1, %1, %4, %4\n v_mad_u32_u24 %2, %2, %4, %4\n v_mad_u32_u24 %3, %3, %4, %4\n"
+                                         : "+v"(*u0), "+v"(*u1), "+v"(*u2), "+v"(*u3) : "v"(c));
+            if (MODE == 19) asm volatile("v_xor_b32 %0, %0, %4\n v_xor_b32 %1, %1, %4\n v_xor_b32 %2, %2, %4\n v_xor_b32 %3, %3, %4\n"
+                                         : "+v"(*u0), "+v"(*u1), "+v"(*u2), "+v"(*u3) : "v"(c));
+            if (MODE == 20) asm volatile("v_lshrrev_b32 %0, %4, %0\n v_lshrrev_b32 %1, %4, %1\n v_lshrrev_b32 %2, %4, %2\n v_lshrrev_b32 %3, %4, %3\n"
+                                         : "+v"(*u0), "+v"(*u1), "+v"(*u2), "+v"(*u3) : "v"(c));
+            if (MODE == 21) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n"
+                                         : "+v"(q0), "+v"(q1) : "v"(c), "v"(*u0) : "vcc");
+            if (MODE == 22) asm volatile("v_readlane_b32 s20, %0, 3\n v_readlane_b32 s21, %1, 3\n v_readlane_b32 s22, %2, 3\n v_readlane_b32 s23, %3, 3\n"
+                                         : : "v"(*u0), "v"(*u1), "v"(*u2), "v"(*u3) : "s20", "s21", "s22", "s23");
         } else if (MODE >= 8) {   // FP64 and transcendental issue rates without conversions in the loop (round 2)
-            static_assert(MODE <= 16, "");
+            static_assert(MODE <= 22, "");
             if (MODE == 8) asm volatile("v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4\n"
                                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(qm));
             if (MODE == 9) asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n"
@@ -105,5 +120,11 @@ int main() {
     run<14>("v_cvt_f32_f64 x4", 4, d);
     run<15>("v_rcp_f32 x4", 4, d);
     run<16>("v_sqrt_f32 x4", 4, d);
+    run<17>("v_mul_lo_u32 x4", 4, d);
+    run<18>("v_mad_u32_u24 x4", 4, d);
+    run<19>("v_xor_b32 x4", 4, d);
+    run<20>("v_lshrrev_b32 x4", 4, d);
+    run<21>("v_mad_u64_u32 x4", 4, d);
+    run<22>("v_readlane_b32 x4", 4, d);
     return 0;
 }
