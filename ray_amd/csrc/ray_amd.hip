@@ -52,12 +52,12 @@ struct DevScene {
     float bg[3];
     FilterGroup sg, tg;                    // exact / filter partition of the sphere and triangle slots (rt_scan.hpp)
     int fast_ok;                           // 0: a primitive is non-finite / out of range -> list-order scan only
-    const float* __restrict__ rect_box;    // [12 per pair of rects] lo x (rect 0, rect 1), lo y, lo z, hi x, hi y, hi z, rounded outwards
+    const float* __restrict__ rect_box;    // [12 per pair of rects] centre x (rect 0, rect 1), y, z, half extent x, y, z (box_pair's form), rounded outwards
     float rect_extent;                     // max |coordinate| of the rects
     const float* __restrict__ rect_bbox;   // [12 per pair of batches] the same around every batch of 16 rects (scenes with >= kRectFlagMin rects:
                                            // the rects are then in spatially compact batches, not sorted by axis)
     const float4* __restrict__ tbvh;       // triangle BVH (null: none), 4 float4 per node: the two children's boxes relative to tg's g as
-                                           // (lo.x0, lo.x1, lo.y0, lo.y1), (lo.z0, lo.z1, hi.x0, hi.x1), (hi.y0, hi.y1, hi.z0, hi.z1), then
+                                           // (C.x0, C.x1, C.y0, C.y1), (C.z0, C.z1, E.x0, E.x1), (E.y0, E.y1, E.z0, E.z1) (centre, half extent), then
                                            // (child 0, child 1, -, -) as int bits: >= 0 inner node, < 0 leaf ~item (an item: tri slots 2i, 2i + 1)
     float tri_extent;                      // max |box coordinate| of the BVH (relative to g)
     int tbvh_leaf_items;                   // a leaf ~s is the run of item slots [s, s + tbvh_leaf_items) (1 up to 32k items; consecutive
@@ -1162,6 +1162,24 @@ void kd_order16(std::vector<int>& order, Coord coord) {
     }
 }
 
+// The device's slab test (box_pair, rt_scan.hpp) takes boxes as centre C and half extent E. Converts an array of lo / hi boxes
+// in place: groups of `group` floats hold `half` lo values followed by `half` hi values; [C - E, C + E] encloses [lo, hi]
+// (C the rounded midpoint, E rounded up); an empty box (lo > hi) gets E = -inf, which no ray needs.
+void boxes_to_centre_half(std::vector<float>& v, size_t group, size_t half) {
+    for (size_t g = 0; g + 2 * half <= v.size(); g += group)
+        for (size_t k = 0; k < half; ++k) {
+            const float lo = v[g + k], hi = v[g + half + k];
+            float c = 0.0f, e = -INFINITY;
+            if (lo <= hi) {
+                c = float(0.5 * (double(lo) + double(hi)));
+                const double ed = std::max(double(hi) - double(c), double(c) - double(lo));
+                e = float(ed);
+                if (double(e) < ed) e = std::nextafterf(e, INFINITY);
+            }
+            v[g + k] = c; v[g + half + k] = e;
+        }
+}
+
 void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k, float margin_k, bool finite, int chunk_words, GroupBuild& out) {
     const int n = int(bound.size());
     std::vector<char> in_filter(n, 0);
@@ -1259,6 +1277,7 @@ void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k
             q[2 * k + fw % 2] = lo; q[6 + 2 * k + fw % 2] = hi;
         }
     }
+    boxes_to_centre_half(out.bnd, 24, 12); boxes_to_centre_half(out.wbnd, 12, 6); boxes_to_centre_half(out.cbnd, 12, 6);
     fg.gx = float(gc[0]); fg.gy = float(gc[1]); fg.gz = float(gc[2]);
     fg.cmax = float(cmax * 1.000001) + 1.0e-30f; fg.r2max = float(r2max * 1.000001);
     fg.margin_k = margin_k;
@@ -1515,6 +1534,7 @@ int rt_upload_scene(const RtScene* s) {
             if (finite && leaves.size() >= 8 && leaves.size() <= (size_t(1) << (kMaskWords - 1))) {
                 Box root;
                 build(0, int(leaves.size()), root);
+                boxes_to_centre_half(nodes, 16, 6);
                 sbvh_nodes.swap(nodes); sgb.fg.sbvh_extent = extent;
             }
         }
@@ -1663,6 +1683,7 @@ int rt_upload_scene(const RtScene* s) {
             } else {
                 build(0, int(leaves.size()), root);
             }
+            boxes_to_centre_half(nodes, 16, 6);
             tbvh_nodes.swap(nodes); tri_extent = extent; tbvh_leaf_items = L;
         }
     }
@@ -1737,6 +1758,7 @@ int rt_upload_scene(const RtScene* s) {
     DevScene ds{};
     ds.n_rect_xy = n_rect_axis[0]; ds.n_rect_xz = n_rect_axis[1]; ds.rect_extent = rect_extent;
     ds.n_sph = int(sph.size()); ds.n_rect = int(rect_axis.size()); ds.n_tri = int(tri_prim.size()); ds.n_prims = s->n_prims;
+    boxes_to_centre_half(rect_box, 12, 6); boxes_to_centre_half(rect_bbox, 12, 6);
     if (upload(sph, &ds.sph) || upload(sph_prim, &ds.sph_prim) || upload(rect, &ds.rect) || upload(rect_f, &ds.rect_f) || upload(rect_box, &ds.rect_box) || upload(rect_bbox, &ds.rect_bbox) || upload(rect_axis, &ds.rect_axis) ||
         upload(rect_prim, &ds.rect_prim) || upload(tri, &ds.tri) || upload(tri_prim, &ds.tri_prim) ||
         upload(prim_kind, &ds.prim_kind) || upload(prim_local, &ds.prim_local) || upload(prim_mat, &ds.prim_mat))

@@ -58,9 +58,9 @@ struct FilterGroup {
     const float* __restrict__ fi;    // [8 n_fpairs] filter group only, per pair x0 x1 y0 y1 z0 z1 k0 k1 (256 B per batch, one base pointer):
                                      // x, y, z = centre - g (pads: 0), k = |centre - g|^2 - r^2 (pads: 3e38)
     const float4* __restrict__ fq;   // spheres only: [2 * all pairs] per pair (cx0,cx1,cy0,cy1), (cz0,cz1,r2_0,r2_1); pads NaN
-    const float* __restrict__ bnd;   // [24 per filter word] boxes of the word's 4 batches, relative to g, item radii included:
-                                     // lo x0..x3, lo y0..y3, lo z0..z3, hi x0..x3, hi y0..y3, hi z0..z3
-    const float* __restrict__ wbnd;  // [12 per pair of filter words] box around each word's batches: lo x (word 0, word 1), lo y, lo z, hi x, hi y, hi z
+    const float* __restrict__ bnd;   // [24 per filter word] boxes of the word's 4 batches, relative to g, item radii included, as centre C
+                                     // and half extent E: C x0..x3, C y0..y3, C z0..z3, E x0..x3, E y0..y3, E z0..z3
+    const float* __restrict__ wbnd;  // [12 per pair of filter words] box around each word's batches: C x (word 0, word 1), C y, C z, E x, E y, E z
     const float* __restrict__ cbnd;  // [12 per pair of chunks] the same around each chunk of chunk_words filter words
     int chunk_words;                 // filter words per chunk: kMaskWords (one flag per pair) or kItemChunkWords (one per item)
     int n_fbatches;                  // batches that hold items (the rest of the last word is padding)
@@ -225,8 +225,9 @@ __device__ __forceinline__ f2 pk_sub_c(f2 c, f2 x) {
 struct FilterRay {
     // level 1: T = bq^2 + Q, bq = od - c.d, Q = (M - a |op|^2) - a k + 2 a op.c
     f2 D01, D2O, NAM, W01, W2;   // (-d.x, -d.y), (-d.z, od), (-a, M - a |op|^2), (2a op.x, 2a op.y), (2a op.z, -)
-    // level 0: t = inv * plane + c per slab plane
-    f2 I01, I2, CX, CY, CZ;      // (inv.x, inv.y), (inv.z, -), (c_lo, c_hi) per axis
+    // level 0 (boxes as centre C and half extent E): per axis u = inv C + k, w = |inv| E + mw; the slab is [u - w, u + w]
+    f2 I01, I2, A01, A2;         // (inv.x, inv.y), (inv.z, -), (|inv.x|, |inv.y|), (|inv.z|, -)
+    f2 KX, KY, KZ;               // per axis (k, mw) = (-o inv, m |inv|): o the origin relative to the boxes' reference point, m the widening
     float t_lo;
 };
 // Slab-test constants (box_pair) of the ray o + t d, o given relative to the boxes' reference point: the boxes are
@@ -236,16 +237,18 @@ __device__ __forceinline__ void set_box_ray(FilterRay& fr, V3 orel, V3 d, float 
     const float ix = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.x), dmin), d.x));
     const float iy = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.y), dmin), d.y));
     const float iz = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.z), dmin), d.z));
+    const float ax = __builtin_fabsf(ix), ay = __builtin_fabsf(iy), az = __builtin_fabsf(iz);
     fr.I01 = f2{ix, iy}; fr.I2 = f2{iz, 0.0f};
-    fr.CX = f2{-(orel.x + m) * ix, -(orel.x - m) * ix};
-    fr.CY = f2{-(orel.y + m) * iy, -(orel.y - m) * iy};
-    fr.CZ = f2{-(orel.z + m) * iz, -(orel.z - m) * iz};
+    fr.A01 = f2{ax, ay}; fr.A2 = f2{az, 0.0f};
+    fr.KX = f2{-orel.x * ix, m * ax};
+    fr.KY = f2{-orel.y * iy, m * ay};
+    fr.KZ = f2{-orel.z * iz, m * az};
     fr.t_lo = t_min >= 0.0 ? 0.0f : -__builtin_inff();
 }
 __device__ __forceinline__ FilterRay filter_ray(const FilterGroup& fg, V3 o, V3 d, float a, float ia, double t_min) {
     FilterRay fr;
     if (fg.n_fpairs == 0) {   // wave-uniform: only always-flagged pairs, the constants are not read
-        fr.D01 = fr.D2O = fr.NAM = fr.W01 = fr.W2 = fr.I01 = fr.I2 = fr.CX = fr.CY = fr.CZ = f2{0.0f, 0.0f};
+        fr.D01 = fr.D2O = fr.NAM = fr.W01 = fr.W2 = fr.I01 = fr.I2 = fr.A01 = fr.A2 = fr.KX = fr.KY = fr.KZ = f2{0.0f, 0.0f};
         fr.t_lo = 0.0f;
         return fr;
     }
@@ -264,33 +267,22 @@ __device__ __forceinline__ FilterRay filter_ray(const FilterGroup& fg, V3 o, V3 
     // boxes hold the items' radii and are widened by 1.01 m, which also covers the rounding of the slab
     // arithmetic and the clamp of direction components below 1e-7 |d|
     const float m = __builtin_amdgcn_sqrtf(M * ia) * 1.01f + 1.0e-30f;
-    const float dmin = 1.0e-7f * __builtin_amdgcn_sqrtf(a);
-    const float ix = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.x), dmin), d.x));
-    const float iy = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.y), dmin), d.y));
-    const float iz = __builtin_amdgcn_rcpf(__builtin_copysignf(__builtin_fmaxf(__builtin_fabsf(d.z), dmin), d.z));
-    fr.I01 = f2{ix, iy}; fr.I2 = f2{iz, 0.0f};
-    fr.CX = f2{-(orel.x + m) * ix, -(orel.x - m) * ix};
-    fr.CY = f2{-(orel.y + m) * iy, -(orel.y - m) * iy};
-    fr.CZ = f2{-(orel.z + m) * iz, -(orel.z - m) * iz};
-    fr.t_lo = t_min >= 0.0 ? 0.0f : -__builtin_inff();
+    set_box_ray(fr, orel, d, a, m, t_min);
     return fr;
 }
 
-// Slab test of the ray's [t_lo, t_hi] against two widened boxes at once: n0 / n1 = this lane needs box 0 / 1
-__device__ __forceinline__ void box_pair(const FilterRay& fr, float t_hi, f2 LX, f2 LY, f2 LZ, f2 HX, f2 HY, f2 HZ, bool& n0, bool& n1) {
-    const f2 x1 = pk_fma_cc<0, 0>(fr.I01, LX, fr.CX), x2 = pk_fma_cc<0, 1>(fr.I01, HX, fr.CX);
-    const f2 y1 = pk_fma_cc<1, 0>(fr.I01, LY, fr.CY), y2 = pk_fma_cc<1, 1>(fr.I01, HY, fr.CY);
-    const f2 z1 = pk_fma_cc<0, 0>(fr.I2, LZ, fr.CZ), z2 = pk_fma_cc<0, 1>(fr.I2, HZ, fr.CZ);
-    {
-        const float tn = vmax3(vmin(x1.x, x2.x), vmin(y1.x, y2.x), vmin(z1.x, z2.x));
-        const float tf = vmin3(vmax(x1.x, x2.x), vmax(y1.x, y2.x), vmax(z1.x, z2.x));
-        n0 = vmax(tn, fr.t_lo) <= vmin(tf, t_hi);
-    }
-    {
-        const float tn = vmax3(vmin(x1.y, x2.y), vmin(y1.y, y2.y), vmin(z1.y, z2.y));
-        const float tf = vmin3(vmax(x1.y, x2.y), vmax(y1.y, y2.y), vmax(z1.y, z2.y));
-        n1 = vmax(tn, fr.t_lo) <= vmin(tf, t_hi);
-    }
+// Slab test of the ray's [t_lo, t_hi] against two widened boxes at once: n0 / n1 = this lane needs box 0 / 1. The boxes come as
+// centre and half extent per axis (C - E, C + E enclose the box; rounded outwards by rt_upload_scene): per axis and box pair one
+// packed FMA each for u = inv C - inv o and w = |inv| E + |inv| m, one packed subtraction and addition for the slab's two ends -
+// no per-box min / max to sort them (v_min_f32 / v_max_f32 cost as much as a packed instruction on gfx950, tools/valu_bench).
+// The rounding of these four operations (a few ulp of |u| + |w|) is covered by the widening m like that of the lo / hi form was.
+__device__ __forceinline__ void box_pair(const FilterRay& fr, float t_hi, f2 CX, f2 CY, f2 CZ, f2 EX, f2 EY, f2 EZ, bool& n0, bool& n1) {
+    const f2 ux = pk_fma_cc<0, 0>(fr.I01, CX, fr.KX), wx = pk_fma_cc<0, 1>(fr.A01, EX, fr.KX);
+    const f2 uy = pk_fma_cc<1, 0>(fr.I01, CY, fr.KY), wy = pk_fma_cc<1, 1>(fr.A01, EY, fr.KY);
+    const f2 uz = pk_fma_cc<0, 0>(fr.I2, CZ, fr.KZ), wz = pk_fma_cc<0, 1>(fr.A2, EZ, fr.KZ);
+    const f2 nx = ux - wx, fx = ux + wx, ny = uy - wy, fy = uy + wy, nz = uz - wz, fz = uz + wz;
+    n0 = vmax(vmax3(nx.x, ny.x, nz.x), fr.t_lo) <= vmin(vmin3(fx.x, fy.x, fz.x), t_hi);
+    n1 = vmax(vmax3(nx.y, ny.y, nz.y), fr.t_lo) <= vmin(vmin3(fx.y, fy.y, fz.y), t_hi);
 }
 
 // The same slab test with the two boxes in VGPRs (every lane looks at its own BVH node) and the entry parameters returned.
@@ -312,23 +304,16 @@ __device__ __forceinline__ f2 pk_fma_cv_v(f2 c, f2 x, f2 a) {
     return r;
 }
 #endif
-__device__ __forceinline__ void box_pair_v(const FilterRay& fr, float t_hi, f2 LX, f2 LY, f2 LZ, f2 HX, f2 HY, f2 HZ, bool& n0, bool& n1, float& e0,
+__device__ __forceinline__ void box_pair_v(const FilterRay& fr, float t_hi, f2 CX, f2 CY, f2 CZ, f2 EX, f2 EY, f2 EZ, bool& n0, bool& n1, float& e0,
                                            float& e1) {
-    const f2 x1 = pk_fma_cc_v<0, 0>(fr.I01, LX, fr.CX), x2 = pk_fma_cc_v<0, 1>(fr.I01, HX, fr.CX);
-    const f2 y1 = pk_fma_cc_v<1, 0>(fr.I01, LY, fr.CY), y2 = pk_fma_cc_v<1, 1>(fr.I01, HY, fr.CY);
-    const f2 z1 = pk_fma_cc_v<0, 0>(fr.I2, LZ, fr.CZ), z2 = pk_fma_cc_v<0, 1>(fr.I2, HZ, fr.CZ);
-    {
-        const float tn = vmax3(vmin(x1.x, x2.x), vmin(y1.x, y2.x), vmin(z1.x, z2.x));
-        const float tf = vmin3(vmax(x1.x, x2.x), vmax(y1.x, y2.x), vmax(z1.x, z2.x));
-        e0 = vmax(tn, fr.t_lo);
-        n0 = e0 <= vmin(tf, t_hi);
-    }
-    {
-        const float tn = vmax3(vmin(x1.y, x2.y), vmin(y1.y, y2.y), vmin(z1.y, z2.y));
-        const float tf = vmin3(vmax(x1.y, x2.y), vmax(y1.y, y2.y), vmax(z1.y, z2.y));
-        e1 = vmax(tn, fr.t_lo);
-        n1 = e1 <= vmin(tf, t_hi);
-    }
+    const f2 ux = pk_fma_cc_v<0, 0>(fr.I01, CX, fr.KX), wx = pk_fma_cc_v<0, 1>(fr.A01, EX, fr.KX);
+    const f2 uy = pk_fma_cc_v<1, 0>(fr.I01, CY, fr.KY), wy = pk_fma_cc_v<1, 1>(fr.A01, EY, fr.KY);
+    const f2 uz = pk_fma_cc_v<0, 0>(fr.I2, CZ, fr.KZ), wz = pk_fma_cc_v<0, 1>(fr.A2, EZ, fr.KZ);
+    const f2 nx = ux - wx, fx = ux + wx, ny = uy - wy, fy = uy + wy, nz = uz - wz, fz = uz + wz;
+    e0 = vmax(vmax3(nx.x, ny.x, nz.x), fr.t_lo);
+    n0 = e0 <= vmin(vmin3(fx.x, fy.x, fz.x), t_hi);
+    e1 = vmax(vmax3(nx.y, ny.y, nz.y), fr.t_lo);
+    n1 = e1 <= vmin(vmin3(fx.y, fy.y, fz.y), t_hi);
 }
 
 // Level 0, chunks: does any lane of the wave need chunk ci (wave-uniform answer)? Groups of one chunk skip the test.

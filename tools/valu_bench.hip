@@ -50,10 +50,28 @@ __global__ __launch_bounds__(256) void k(float* out, float seed) {
                                          : "+v"(*u0), "+v"(*u1), "+v"(*u2), "+v"(*u3) : "v"(c));
             if (MODE == 21) asm volatile("v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n v_mad_u64_u32 %0, vcc, %2, %3, %0\n v_mad_u64_u32 %1, vcc, %2, %3, %1\n"
                                          : "+v"(q0), "+v"(q1) : "v"(c), "v"(*u0) : "vcc");
+            if (MODE == 23) asm volatile("v_fmac_f32 %0, %4, %4\n v_fmac_f32 %1, %4, %4\n v_fmac_f32 %2, %4, %4\n v_fmac_f32 %3, %4, %4\n"
+                                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));
+            if (MODE == 24) asm volatile("v_max_f32 %0, %0, %4\n v_max_f32 %1, %1, %4\n v_min_f32 %2, %2, %4\n v_min_f32 %3, %3, %4\n"
+                                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));
+            if (MODE == 25) asm volatile("v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n"
+                                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m) : "vcc");
+            if (MODE == 26) asm volatile("v_cmp_lt_f32 vcc, %0, %4\n v_cmp_lt_f32 vcc, %1, %4\n v_cmp_lt_f32 vcc, %2, %4\n v_cmp_lt_f32 vcc, %3, %4\n"
+                                         : : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(m) : "vcc");
+            if (MODE == 27) asm volatile("v_mov_b32 %0, %4\n v_mov_b32 %1, %4\n v_mov_b32 %2, %4\n v_mov_b32 %3, %4\n"
+                                         : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(m));
+            if (MODE == 28) asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_sub_f32 %2, %2, %4\n v_sub_f32 %3, %3, %4\n"
+                                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));
+            if (MODE == 29) asm volatile("v_max3_f32 %0, %0, %4, %4\n v_max3_f32 %1, %1, %4, %4\n v_min3_f32 %2, %2, %4, %4\n v_min3_f32 %3, %3, %4, %4\n"
+                                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(m));
+            if (MODE == 30) asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4\n"
+                                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "s"(pm));
+            if (MODE == 31) asm volatile("v_fma_f32 %0, %0, %1, %0\n v_fma_f32 %0, %0, %1, %0\n v_fma_f32 %0, %0, %1, %0\n v_fma_f32 %0, %0, %1, %0\n"
+                                         : "+v"(a0) : "v"(m));
             if (MODE == 22) asm volatile("v_readlane_b32 s20, %0, 3\n v_readlane_b32 s21, %1, 3\n v_readlane_b32 s22, %2, 3\n v_readlane_b32 s23, %3, 3\n"
                                          : : "v"(*u0), "v"(*u1), "v"(*u2), "v"(*u3) : "s20", "s21", "s22", "s23");
         } else if (MODE >= 8) {   // FP64 and transcendental issue rates without conversions in the loop (round 2)
-            static_assert(MODE <= 22, "");
+            static_assert(MODE <= 31, "");
             if (MODE == 8) asm volatile("v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4\n"
                                         : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(qm));
             if (MODE == 9) asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n"
@@ -97,7 +115,7 @@ void run(const char* name, int ops_per_iter, float* d) {
     double lane_ops = double(grid) * 256 * N_ITER * 4.0 * ops_per_iter;
     // cycles per wave-instruction on one SIMD: 8 waves per SIMD share it; clock from the device
     int dev = 0, khz = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&khz, hipDeviceAttributeClockRate, dev);
-    const double instr_per_wave = double(N_ITER) * 4.0 * (MODE == 1 || MODE == 3 || MODE == 5 ? ops_per_iter / 2 : ops_per_iter);
+    const double instr_per_wave = double(N_ITER) * 4.0 * (MODE == 1 || MODE == 3 || MODE == 5 || MODE == 30 ? ops_per_iter / 2 : ops_per_iter);
     const double cyc = ms * 1e-3 * khz * 1e3 / (instr_per_wave * 8.0);
     printf("%-28s %8.3f ms  %7.2f T lane-ops/s  %6.2f cycles per wave-instruction (8 waves/SIMD, %d MHz)\n", name, ms, lane_ops / (ms * 1e-3) / 1e12, cyc, khz / 1000);
 }
@@ -126,5 +144,14 @@ int main() {
     run<20>("v_lshrrev_b32 x4", 4, d);
     run<21>("v_mad_u64_u32 x4", 4, d);
     run<22>("v_readlane_b32 x4", 4, d);
+    run<23>("v_fmac_f32 (VOP2) x4", 4, d);
+    run<24>("v_max/min_f32 (VOP2) x4", 4, d);
+    run<25>("v_cndmask_b32 vcc x4", 4, d);
+    run<26>("v_cmp_lt_f32 vcc x4", 4, d);
+    run<27>("v_mov_b32 x4", 4, d);
+    run<28>("v_add/sub_f32 vgpr x4", 4, d);
+    run<29>("v_max3/min3_f32 x4", 4, d);
+    run<30>("v_pk_fma_f32 sgpr-pair x4 (8 fma)", 8, d);
+    run<31>("v_fma_f32 dependent chain x4", 4, d);
     return 0;
 }
