@@ -753,7 +753,23 @@ struct RenderArgs {
     unsigned long long* stamps;                    // RT_STAMPS diagnostic builds: [12] section cycles and pass counts
     const int* __restrict__ pixels;                // PIXELS kernels: [n_pixels] pixel indices y * W + x to render
     int n_pixels;
+    double inv_w, inv_h;                           // 1 / double(float(W)), 1 / double(float(H)), correctly rounded (host): see jitter_div
 };
+
+// (x + xi) / float(W) of rayview.cpp:80-81 without the FP32 division sequence: float(double(n) * inv) with inv = RN(1 / double(float(W))).
+// This IS the IEEE quotient float(n) / float(W): the double product is within 2^-52 (relative) of the exact quotient Q of the two
+// floats, and Q is either a float itself or at least 2^-49 Q away from every midpoint between adjacent floats (Q = X / Y 2^e with
+// 24-bit integers X, Y: |X / Y - (2 j + 1) / 2^k| = |X 2^k - (2 j + 1) Y| / (Y 2^k) >= 2^-49 unless the numerator is 0, which needs
+// 2^k | Y, i.e. Y a power of two, where the product is exact). n is 0 or in [2^-24, 2^31), W in [1, 2^31]: no result is subnormal.
+RT_DEV float jitter_div(float n, float w, double inv) {
+#ifdef __HIP_DEVICE_COMPILE__
+    (void)w;
+    return float(double(n) * inv);
+#else
+    (void)inv;
+    return n / w;
+#endif
+}
 
 // The render kernel's arguments as they lie in the kernarg segment. Values that one section of the main loop needs are read from
 // there (scalar loads through the constant address space) where they are used, behind a pointer the compiler cannot see through:
@@ -844,8 +860,8 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
         if (have && !path) {
             const RenderArgs ra = load_kernarg<RenderArgs>(offsetof(RenderKernArgs, ra));
             g.key(ra.seed, pix, uint32_t(s));
-            float u = (float(x) + g.u01()) / float(ra.W);
-            float v = (float(y) + g.u01()) / float(ra.H);
+            float u = jitter_div(float(x) + g.u01(), float(ra.W), ra.inv_w);
+            float v = jitter_div(float(y) + g.u01(), float(ra.H), ra.inv_h);
             const DevCamera cam_here = load_kernarg<DevCamera>(offsetof(RenderKernArgs, cam));
             ray = get_ray(cam_here, g, u, v);
             level = 0; depth_left = ra.depth; path = true;
@@ -1928,6 +1944,7 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     ra.W = w; ra.H = h; ra.y_begin = y_begin; ra.y_count = y_count; ra.spp_begin = spp_begin; ra.spp_count = spp_count; ra.depth = depth;
     ra.band_first = band_first; ra.band_stride = band_stride; ra.tiles_y = tiles_y;
     ra.seed = seed; ra.flags = flags;
+    ra.inv_w = 1.0 / double(float(w)); ra.inv_h = 1.0 / double(float(h));
     ra.accum = reinterpret_cast<float4*>(d_accum); ra.stack = stack;
     ra.rays_out = reinterpret_cast<unsigned long long*>(d_rays);
     ra.work_counter = static_cast<unsigned int*>(counters);
@@ -2018,6 +2035,7 @@ int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_b
     ra.W = w; ra.H = h; ra.y_begin = 0; ra.y_count = h; ra.spp_begin = spp_begin; ra.spp_count = spp_count; ra.depth = depth;
     ra.band_first = 0; ra.band_stride = 1; ra.tiles_y = 0;
     ra.seed = seed; ra.flags = flags;
+    ra.inv_w = 1.0 / double(float(w)); ra.inv_h = 1.0 / double(float(h));
     ra.accum = reinterpret_cast<float4*>(d_accum); ra.stack = static_cast<float4*>(G().stack);
     ra.rays_out = reinterpret_cast<unsigned long long*>(d_rays);
     ra.work_counter = static_cast<unsigned int*>(G().counters);
