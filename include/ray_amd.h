@@ -194,7 +194,10 @@ int rt_render_bands(int w, int h, int band_first, int band_stride, int spp_begin
  * rt_render computes them, its accumulator entry is overwritten (added to with RT_RENDER_ACCUMULATE), and
  * no other pixel is touched. A pixel listed twice is rendered twice: overwriting, both writes carry the same
  * values; with RT_RENDER_ACCUMULATE each listing adds its sums and its sample count once (atomic adds of
- * identical values, so the result does not depend on their order). An index outside [0, w*h) is skipped.   */
+ * identical values, so the result does not depend on their order). An index outside [0, w*h) is skipped.
+ * The ORDER of the list does not matter for the result and, from 2048 entries on, not for the speed either: the
+ * library renders a copy sorted by 8x8 tile (device-side radix sort on the same stream, in a workspace that it
+ * allocates once and grows when a longer list comes); d_pixels itself is only read.                         */
 int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_begin, int spp_count, int depth,
                      uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
 

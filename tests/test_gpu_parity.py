@@ -955,3 +955,40 @@ def test_triangle_bvh_forced_on_small_and_odd_scenes(rt):
         assert rt.verify_mismatches() == 0 and rays > 480 * 270
     finally:
         os.environ.pop("RT_TRI_BVH_MIN", None)
+
+
+@pytest.mark.parametrize("W,H", [(320, 180), (250, 37)])
+def test_render_pixels_long_lists_are_sorted_by_tile_first(rt, W, H):
+    """Lists of 2048 pixels and more are sorted by 8x8 tile on the device before they are rendered (random order costs the
+    485-sphere frame 43 %, tools/pixels_order.py). The sort must not show: every listed pixel gets the frame's sums, a pixel
+    listed k times gets k times them under RT_RENDER_ACCUMULATE, indices outside the frame are skipped, nothing else is
+    written, the caller's list is left as it was, and a second call with a shorter list reuses the workspace."""
+    from ray_amd import api
+    sc = scenes.get_scene("random", half=3)
+    rt.upload_scene(sc)
+    spp, depth = 2, 8
+    full, _ = rt.render(W, H, spp, depth, seed=77)
+    f = full.reshape(-1, 4)
+    rng = np.random.default_rng(W)
+    for n in (30000, 2048, 5000):
+        px = rng.integers(0, W * H, n).astype(np.int32)
+        px[rng.integers(0, n, 40)] = rng.choice(np.array([-1, W * H, W * H + 3, 2 ** 31 - 1, -2 ** 31], np.int32), 40)
+        valid = px[(px >= 0) & (px < W * H)]
+        counts = np.bincount(valid, minlength=W * H)
+        dpx = rt.alloc(px.nbytes).from_numpy(px)
+        acc = rt.alloc((W * H + 16) * 16).zero()
+        rays = rt.alloc(8).zero()
+        rt.render_pixels(W, H, acc, dpx, spp, depth, seed=77, rays=rays)
+        got = acc.to_numpy(np.float32, (W * H + 16, 4))
+        assert O.same_values(got[:W * H][counts > 0], f[counts > 0])
+        assert (got[:W * H][counts == 0] == 0).all() and (got[W * H:] == 0).all()
+        assert np.array_equal(dpx.to_numpy(np.int32, (n,)), px)
+        acc.zero()
+        rt.render_pixels(W, H, acc, dpx, spp, depth, seed=77, flags=api.RENDER_ACCUMULATE)
+        got = acc.to_numpy(np.float32, (W * H + 16, 4))
+        want = np.zeros((W * H, 4), np.float32)
+        for k in range(1, int(counts.max()) + 1):
+            sel = counts >= k
+            want[sel] = want[sel] + f[sel]
+        assert O.same_values(got[:W * H], want) and (got[W * H:] == 0).all()
+        acc.free(); dpx.free(); rays.free()
