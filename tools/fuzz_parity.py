@@ -83,9 +83,37 @@ for i in range(n_cases):
     oacc, orays = O.render(sc, W, H, spp, depth, rng_mode=1, seed64=seed, math_mode=1)
     ok = rays == orays and O.same_bits_or_nan(acc, oacc)
     total_rays += rays
+    what = ""
+    if ok and i % 4 == 0:       # the other entry points on the same scene: primary ids / t, closest hits of random rays, radiance of random rays, a pixel list
+        prim, t = ctx.primary_hits(W, H, seed=seed)
+        oprim, ot = O.primary(sc, W, H, rng_mode=1, seed=seed)
+        if not (np.array_equal(prim, oprim) and O.bits_equal(t, ot)):
+            ok, what = False, "primary_hits"
+        n = 600
+        ro = rng.uniform(-6, 6, (n, 3)).astype(np.float32); ro[:, 2] -= 1.0
+        rd = rng.standard_normal((n, 3)).astype(np.float32)
+        rd[::17, int(rng.integers(0, 3))] = 0.0
+        t_min, t_max = [(0.001, np.inf), (-3.0, 25.0), (0.5, 7.0)][int(rng.integers(0, 3))]
+        got = ctx.hit_rays(ro, rd, t_min, t_max)
+        ref = O.hit_rays(sc, ro, rd, t_min, t_max)
+        if not (np.array_equal(got[0], ref[0]) and O.bits_equal(got[1], ref[1]) and all(O.same_bits_or_nan(a, b) for a, b in zip(got[2:4], ref[2:4]))
+                and np.array_equal(got[4], ref[4])):
+            ok, what = False, what + " hit_rays"
+        g = ctx.trace_rays(ro, rd, depth, seed=seed & 0xffffffff)
+        r = O.trace_rays(sc, ro, rd, depth, seed=seed & 0xffffffff)
+        if not O.same_bits_or_nan(g, r):
+            ok, what = False, what + " trace_rays"
+        px = rng.integers(0, W * H, int(rng.integers(1, 4000))).astype(np.int32)
+        a2 = ctx.alloc(W * H * 16).zero()
+        ctx.render_pixels(W, H, a2, px, spp, depth, seed=seed)
+        g2 = a2.to_numpy(np.float32, (H, W, 4)).reshape(-1, 4); a2.free()
+        m = np.zeros(W * H, bool); m[px] = True
+        if not (O.same_bits_or_nan(g2[m], acc.reshape(-1, 4)[m]) and (g2[~m] == 0).all()):
+            ok, what = False, what + " render_pixels"
     if not ok:
         bad += 1
         diff = int((acc.view(np.uint32) != oacc.view(np.uint32)).sum())
+        print("   failing:", what or "render")
     print(f"case {i:3d} {name:8s} prims {sc.flatten()['n_prims']:5d} {W}x{H} spp {spp} depth {depth:2d} rays {rays:8d} {'ok' if ok else 'MISMATCH (%d words, rays %d vs %d)' % (diff, rays, orays)}", flush=True)
 print(f"{n_cases} cases, {total_rays} rays, {bad} mismatching frames, {time.time() - t0:.0f} s")
 ctx.close()
