@@ -740,6 +740,7 @@ __device__ __forceinline__ V3 trace_path(const DevScene& sc, Ray ray, Rng& g, in
 // ================================================================================================
 constexpr int kBlock = kScanBlock;   // 4 waves
 constexpr int kTile = 8;             // work unit handed to a wave: one 8x8 pixel tile
+constexpr uint32_t kNoTail = 0xffffffffu;
 
 struct RenderArgs {
     int W, H, y_begin, y_count, spp_begin, spp_count, depth;
@@ -755,6 +756,12 @@ struct RenderArgs {
     const int* __restrict__ pixels;                // PIXELS kernels: [n_pixels] pixel indices y * W + x to render
     int n_pixels;
     double inv_w, inv_h;                           // 1 / double(float(W)), 1 / double(float(H)), correctly rounded (host): see jitter_div
+    // The end of the frame in finer units (render_kernel "tail"): n_tail_tiles tiles, every tail_stride-th of the frame (tile
+    // tt * tail_stride + tail_stride - 1), are handed out after the other n_bulk_tiles, as tail_chunks units of tail_chunk samples
+    // per pixel whose colours go to `tail` and are summed in sample order by tail_sum_kernel. n_tail_tiles = 0: no tail (the
+    // PIXELS kernels, rt_render_noalloc, frames of few samples).
+    int n_bulk_tiles, n_tail_tiles, tail_chunk, tail_chunks, tail_stride;
+    float4* __restrict__ tail;                     // [n_tail_tiles][spp_count][64] colour of sample s of pixel `in` of tail tile t
 };
 
 // (x + xi) / float(W) of rayview.cpp:80-81 without the FP32 division sequence: float(double(n) * inv) with inv = RN(1 / double(float(W))).
@@ -792,6 +799,12 @@ static_assert(offsetof(RenderKernArgs, sc) == 0, "closest_hit<..., KARG> reads t
 // refilled with one 8x8 tile from a global counter (one atomic per wave and tile).
 // PIXELS: the work items are the entries of a caller-supplied pixel list (RayView::renderOneRay's random
 // pixels, rayview.cpp:69-70) instead of the tiles of a row range.
+// The tail. A lane's unit of work is a whole pixel, so a frame ends with every lane finishing the pixel it happens to hold: for
+// about one pixel's time lanes run dry one by one, waves over cheap pixels leave, and a 1080p frame of 64 samples (8 pixels
+// per lane in all) spends 10 - 20 % of its time that way (tools/tail_probe.py). The frame's last tiles are therefore handed
+// out in units of a few SAMPLES per pixel: a lane renders samples [s, s_end) of its pixel and stores each colour to ra.tail
+// instead of adding it up; tail_sum_kernel then adds a pixel's colours in sample order, exactly as the lane would have
+// (rayview.cpp:79-84 sums in order). The colour of a sample depends on (seed, pixel, sample) only, so the frame is bit-identical.
 template <bool VERIFY, bool PIXELS = false, int RECTS = 0, int MEDIA = 0, int TRIS = 0>
 __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra_entry) {
     __shared__ RT_WORDS_ALIGN uint32_t s_words[kMaskWords * kBlock];
@@ -802,12 +815,15 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
     const Recip64 rpi = recip64(kPi);
 
     bool have = false, path = false;
-    int x = 0, y = 0, s = 0, level = 0, depth_left = 0;
+    int x = 0, y = 0, s = 0, s_end = 0, level = 0, depth_left = 0;
     uint32_t pix = 0, n_rays = 0;
+    uint32_t tail_at = kNoTail;    // tail units: index into ra.tail of this lane's pixel at sample spp_begin (kNoTail: a whole pixel, summed here)
     V3 sum = v3(0.0f, 0.0f, 0.0f);
     Ray ray = make_ray(v3(0, 0, 0), v3(0, 0, 0));
     Rng g; g.state = 0;
-    int q_cur = 0, q_end = 0;      // wave-uniform: the wave's queue of work indices
+    int q_cur = 0, q_end = 0;      // wave-uniform: the wave's queue of work indices (one unit of 64 at a time), and what the unit is:
+    int q_x0 = 0, q_y0 = 0, q_s0 = 0, q_s1 = 0;   // its tile's first pixel, its samples [q_s0, q_s1)
+    uint32_t q_at = kNoTail;                      // tail units: index into ra.tail of the tile's first pixel at sample spp_begin
     bool exhausted = false;        // wave-uniform: the global counter has run past the last tile
 #ifdef RT_STAMPS
     Stamps stp{};
@@ -820,8 +836,8 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
             const unsigned long long need = __ballot(!have);
             if (need == 0ull) break;
             const RenderArgs ra = load_kernarg<RenderArgs>(offsetof(RenderKernArgs, ra));   // (every section reads its arguments where it uses them)
-            const int tiles_x = (ra.W + kTile - 1) / kTile;
-            const int total = PIXELS ? ra.n_pixels : tiles_x * ra.tiles_y * 64;
+            const int bulk_items = PIXELS ? ra.n_pixels : ra.n_bulk_tiles * 64;
+            const int total = PIXELS ? ra.n_pixels : bulk_items + ra.n_tail_tiles * ra.tail_chunks * 64;
             if (q_cur >= q_end) {
                 if (exhausted) break;
                 int base = 0;
@@ -829,6 +845,24 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (base >= total) { exhausted = true; break; }
                 q_cur = base; q_end = base + 64;
+                if (!PIXELS) {   // what the unit is: once per unit, on wave-uniform values
+                    const int tiles_x = (ra.W + kTile - 1) / kTile;
+                    int tile;
+                    q_s0 = ra.spp_begin; q_s1 = ra.spp_begin + ra.spp_count; q_at = kNoTail;
+                    if (base < bulk_items) {   // a whole tile: the b-th tile that is not a tail tile
+                        const int b = base >> 6;
+                        tile = b < ra.n_tail_tiles * (ra.tail_stride - 1) ? b + b / (ra.tail_stride - 1) : b + ra.n_tail_tiles;
+                    } else {                   // tail_chunk samples of tail tile tt = every tail_stride-th tile of the frame
+                        const int unit = (base - bulk_items) >> 6;
+                        const int tt = unit / ra.tail_chunks, ch = unit - tt * ra.tail_chunks;
+                        tile = tt * ra.tail_stride + ra.tail_stride - 1;
+                        q_s0 += ch * ra.tail_chunk;
+                        q_s1 = q_s0 + ra.tail_chunk < q_s1 ? q_s0 + ra.tail_chunk : q_s1;
+                        q_at = uint32_t(tt) * uint32_t(ra.spp_count) * 64u;
+                    }
+                    q_x0 = (tile % tiles_x) * kTile;
+                    q_y0 = ra.y_begin + (ra.band_first + (tile / tiles_x) * ra.band_stride) * kTile;
+                }
             }
             const int rank = __popcll(need & ((1ull << lane) - 1ull));
             const int avail = q_end - q_cur;
@@ -841,15 +875,17 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
                     inside = inside && uint32_t(p) < uint32_t(ra.W) * uint32_t(ra.H);   // an index outside the frame is skipped, never written
                     y = p / ra.W; x = p - y * ra.W;
                 } else {
-                    const int tile = idx >> 6, in = idx & 63;
-                    x = (tile % tiles_x) * kTile + (in & 7);
-                    y = ra.y_begin + (ra.band_first + (tile / tiles_x) * ra.band_stride) * kTile + (in >> 3);
+                    const int in = idx & 63;
+                    x = q_x0 + (in & 7);
+                    y = q_y0 + (in >> 3);
                     inside = x < ra.W && y < ra.y_begin + ra.y_count;
                 }
                 if (inside) {
                     have = true; path = false;
                     pix = uint32_t(y) * uint32_t(ra.W) + uint32_t(x);
-                    s = ra.spp_begin;
+                    s = PIXELS ? ra.spp_begin : q_s0;
+                    s_end = PIXELS ? ra.spp_begin + ra.spp_count : q_s1;
+                    tail_at = PIXELS || q_at == kNoTail ? kNoTail : q_at + uint32_t(idx & 63);
                     sum = v3(0.0f, 0.0f, 0.0f);
                 }
             }
@@ -874,7 +910,6 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
         if (path) {
             const RenderArgs ra = load_kernarg<RenderArgs>(offsetof(RenderKernArgs, ra));
             const bool normals = (ra.flags & RT_RENDER_NORMALS) != 0;
-            const int spp_end = ra.spp_begin + ra.spp_count;
             ++n_rays;
             Hit h = closest_hit<RECTS, MEDIA, TRIS, true>(sc_scan, ray, double(0.001f), kInf, g, words RT_STAMP_ARG);   // calc.cpp:99
             if (VERIFY) {   // scenes with a constant_medium (which draws inside the scan) are rejected for VERIFY by the host
@@ -890,9 +925,14 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
             }
             RT_STAMP(5);
             if (done) {
-                sum = sum + unwind_path(st, level, L);                        // rayview.cpp:83
+                const V3 colour = unwind_path(st, level, L);
+                const bool whole = PIXELS || tail_at == kNoTail;
+                if (whole) sum = sum + colour;                                // rayview.cpp:83
+                else ra.tail[tail_at + uint32_t(s - ra.spp_begin) * 64u] = make_float4(colour.x, colour.y, colour.z, 0.0f);
                 path = false;
-                if (++s == spp_end) {
+                ++s;
+                if (s == s_end && !whole) have = false;
+                if (s == s_end && whole) {
                     float4 a = make_float4(sum.x, sum.y, sum.z, float(ra.spp_count));
                     if (PIXELS && (ra.flags & RT_RENDER_ACCUMULATE)) {
                         // a pixel may be listed more than once (the reference draws its pixels at random, rayview.cpp:69-70):
@@ -923,6 +963,34 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0 && v) atomicAdd(ra_entry.rays_out, v);
     }
+}
+
+// The tail tiles of a frame (render_kernel): one thread per pixel adds the stored colours of its samples in sample order, as
+// the lane that renders a whole pixel does (rayview.cpp:79-84), and writes the accumulator the same way. A wave is one tile:
+// the 64 lanes read 1 KB of consecutive colours per sample.
+__global__ __launch_bounds__(256) void tail_sum_kernel(RenderArgs ra) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int tt = idx >> 6, in = idx & 63;
+    if (tt >= ra.n_tail_tiles) return;
+    const int tiles_x = (ra.W + kTile - 1) / kTile;
+    const int tile = tt * ra.tail_stride + ra.tail_stride - 1;
+    const int x = (tile % tiles_x) * kTile + (in & 7);
+    const int y = ra.y_begin + (ra.band_first + (tile / tiles_x) * ra.band_stride) * kTile + (in >> 3);
+    if (!(x < ra.W && y < ra.y_begin + ra.y_count)) return;
+    const float4* __restrict__ c = ra.tail + (size_t(tt) * size_t(ra.spp_count) * 64u + size_t(in));
+    V3 sum = v3(0.0f, 0.0f, 0.0f);
+#pragma unroll 8
+    for (int s = 0; s < ra.spp_count; ++s) {
+        const float4 v = c[size_t(s) * 64u];
+        sum = sum + v3(v.x, v.y, v.z);
+    }
+    const uint32_t pix = uint32_t(y) * uint32_t(ra.W) + uint32_t(x);
+    float4 a = make_float4(sum.x, sum.y, sum.z, float(ra.spp_count));
+    if (ra.flags & RT_RENDER_ACCUMULATE) {
+        const float4 o = ra.accum[pix];
+        a = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + float(ra.spp_count));
+    }
+    ra.accum[pix] = a;
 }
 
 // rt_render_pixels: the 8x8 tile of every listed pixel (the key the list is sorted by before it is rendered); a pixel
@@ -1097,6 +1165,8 @@ struct Context {
     size_t stack_bytes = 0;
     void* counters = nullptr;   // [0] unsigned int: tile counter of render_kernel; [8] unsigned long long: verify mismatches
     int render_blocks_per_cu = 0;
+    void* tail = nullptr;               // colours of the frame's tail tiles (render_kernel, tail_sum_kernel; grow-only)
+    size_t tail_bytes = 0;
     void* pix_sort = nullptr;           // rt_render_pixels: tile keys in / out, sorted pixel indices, radix-sort workspace (grow-only)
     size_t pix_sort_bytes = 0;
     hipStream_t own_stream = nullptr;   // created by rt_init; `stream` is this one unless rt_set_stream handed in the caller's
@@ -1396,6 +1466,8 @@ void rt_shutdown(void) {
     G().counters = nullptr;
     if (G().pix_sort) (void)hipFree(G().pix_sort);
     G().pix_sort = nullptr; G().pix_sort_bytes = 0;
+    if (G().tail) (void)hipFree(G().tail);
+    G().tail = nullptr; G().tail_bytes = 0;
     (void)hipEventDestroy(G().ev0); (void)hipEventDestroy(G().ev1);
     (void)hipStreamDestroy(G().own_stream);
     G().own_stream = nullptr; G().stream = nullptr;
@@ -1944,8 +2016,35 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     if (const char* e = getenv("RT_BPC")) resident = G().prop.multiProcessorCount * atoi(e);   // diagnostic: blocks per CU
 #endif
     if (settle()) return 1;   // a launch still in flight owns the counters and the stack
-    const int want = (n_tiles + 3) / 4;
-    int grid = want < resident ? want : resident;
+    // The tail (render_kernel): n_tail tiles spread over the frame are handed out last, as units of `chunk` samples per pixel.
+    // To keep every lane fed until the last whole pixel is done they must hold about as much work as the frame's most
+    // expensive pixel takes on every lane - several tiles per wave; measured (tools/tail_sweep.py, 1080p at 64 samples, 8 tiles
+    // per wave): half the frame is best (the 9.8k-triangle frame 68 -> 53 ms), all of it 5 % worse again (a lane then asks for work
+    // every few samples). So: half the frame, at most 4 tiles per resident wave, all of a frame of at most 2 tiles per wave, and
+    // no more than a colour buffer of 2 GiB holds (16 bytes per sample: 8192 tiles at 256 samples).
+    int chunk = 8, n_tail = 0, chunks = 1;
+    if (const char* e = getenv("RT_TAIL_CHUNK")) { const int c = atoi(e); if (c >= 1) chunk = c; }   // (the two switches: tests and tools/tail_sweep.py)
+    if (!scratch_dev && spp_count >= 2 * chunk) {
+        const long long waves = (long long)resident * (kBlock / 64);
+        long long t = n_tiles <= 2 * waves ? n_tiles : (n_tiles / 2 < 4 * waves ? n_tiles / 2 : 4 * waves);
+        if (const char* e = getenv("RT_TAIL_TILES")) { t = atoll(e); if (t > n_tiles) t = n_tiles; if (t < 0) t = 0; }
+        const long long per_tile = (long long)spp_count * 64 * (long long)sizeof(float4);
+        const long long cap = (2ll << 30) / per_tile;
+        if (t > cap) t = cap;
+        chunks = (spp_count + chunk - 1) / chunk;
+        if (t * chunks * 64 + (long long)(n_tiles - t) * 64 > 0x7fffff00ll) t = 0;   // the work counter is 32 bits wide
+        n_tail = int(t);
+        if (n_tail > 0 && size_t(n_tail * per_tile) > G().tail_bytes) {
+            if (G().tail) HIP_OK(hipFree(G().tail));
+            G().tail = nullptr; G().tail_bytes = 0;
+            HIP_OK(hipMalloc(&G().tail, size_t(n_tail * per_tile)));
+            G().tail_bytes = size_t(n_tail * per_tile);
+        }
+    }
+    if (n_tail == 0) chunks = 1;
+    const long long units = (long long)(n_tiles - n_tail) + (long long)n_tail * chunks;
+    const long long want = (units + 3) / 4;
+    int grid = want < resident ? int(want) : resident;
     void* counters = G().counters;
     float4* stack = nullptr;
     if (scratch_dev) {   // the stack part of `scratch` holds kNoAllocMaxDepth - kLdsLevels levels of kNoAllocMaxGrid blocks
@@ -1962,6 +2061,9 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     ra.seed = seed; ra.flags = flags;
     ra.inv_w = 1.0 / double(float(w)); ra.inv_h = 1.0 / double(float(h));
     ra.accum = reinterpret_cast<float4*>(d_accum); ra.stack = stack;
+    ra.n_bulk_tiles = n_tiles - n_tail; ra.n_tail_tiles = n_tail; ra.tail_chunk = chunk; ra.tail_chunks = chunks;
+    ra.tail_stride = n_tail > 0 ? n_tiles / n_tail : 1;
+    ra.tail = static_cast<float4*>(G().tail);
     ra.rays_out = reinterpret_cast<unsigned long long*>(d_rays);
     ra.work_counter = static_cast<unsigned int*>(counters);
     ra.mismatches = reinterpret_cast<unsigned long long*>(static_cast<char*>(counters) + 8);
@@ -1985,7 +2087,8 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     else if (verify) hipLaunchKernelGGL((render_kernel<true, false, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     else if (many_rects) hipLaunchKernelGGL((render_kernel<false, false, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     else hipLaunchKernelGGL((render_kernel<false, false, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
-    return finish_timed(1, (flags & RT_RENDER_NOWAIT) != 0);
+    if (n_tail > 0) hipLaunchKernelGGL(tail_sum_kernel, dim3((n_tail * 64 + 255) / 256), dim3(256), 0, G().stream, ra);
+    return finish_timed(n_tail > 0 ? 2 : 1, (flags & RT_RENDER_NOWAIT) != 0);
 }
 
 int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth, uint64_t seed, uint32_t flags,
