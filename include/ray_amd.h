@@ -162,7 +162,13 @@ int rt_hit_rays(int64_t n, const float* d_origin, const float* d_dir, double t_m
  * numbers. d_accum is [h][w][4] floats (r, g, b sums in sample order; .w = number of samples
  * accumulated), indexed by the un-mirrored (x, y) of renderOneRay. d_rays (may be NULL) receives
  * the number of closest-hit scans executed (primary + bounce rays), added atomically.
- * Pixels outside [y_begin, y_begin + y_count) are not touched (image-tile split).                 */
+ * Pixels outside [y_begin, y_begin + y_count) are not touched (image-tile split).
+ * Device memory the call keeps in the context (grown on demand, freed by rt_shutdown): the path stack beyond
+ * six bounces, and, for spp_count >= 16, a colour buffer for the end of the frame: the last part of a frame is
+ * rendered in units of 8 samples per pixel whose colours (16 bytes each) a second kernel adds in sample order -
+ * the same bits as a pixel summed by one thread, without the idle lanes of a frame that ends pixel by pixel.
+ * Its size is 64 KiB x spp_count / 64 per 8x8 tile for up to half the frame's tiles, at most 4 GiB (environment
+ * RT_TAIL_MAX_MB; 0 = none); a device that cannot spare it gets a smaller one or none, with the same result.      */
 int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth,
               uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
 
@@ -171,7 +177,8 @@ int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_cou
  * kernels and bit-identical results as rt_render, but the kernel's scratch (the tile counter and the HBM part
  * of the per-thread path stack, which rt_render keeps in buffers it allocates and grows on demand) lives in a
  * file-scope device array of the library: 40 MiB + 256 B on every GPU the library is bound to, held until the
- * process ends. The call makes no hipMalloc / hipFree and calls no allocating routine.
+ * process ends. The call makes no hipMalloc / hipFree and calls no allocating routine (so it also renders the
+ * end of the frame as whole pixels, without rt_render's colour buffer: same result, a slower last part).
  * Limits: depth <= 16 (RT_NOALLOC_MAX_DEPTH; deeper paths are rejected with an error, use rt_render);
  * RT_RENDER_VERIFY is rejected. Every call on one GPU shares that GPU's array: calls that overlap in time on
  * one GPU race (the library issues them on one stream, so calls from one host thread never do).             */

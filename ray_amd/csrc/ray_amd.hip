@@ -2021,7 +2021,8 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     // expensive pixel takes on every lane - several tiles per wave; measured (tools/tail_sweep.py, 1080p at 64 samples, 8 tiles
     // per wave): half the frame is best (the 9.8k-triangle frame 68 -> 53 ms), all of it 5 % worse again (a lane then asks for work
     // every few samples). So: half the frame, at most 4 tiles per resident wave, all of a frame of at most 2 tiles per wave, and
-    // no more than a colour buffer of 2 GiB holds (16 bytes per sample: 8192 tiles at 256 samples).
+    // no more than a colour buffer of 4 GiB holds (16 bytes per sample: 16384 tiles at 256 samples; the 4K frame of 256 samples
+    // takes 420 ms without a tail, 416 / 412 / 408 ms with 1 / 2 / 4 GiB). RT_TAIL_MAX_MB changes the limit, 0 = no tail.
     int chunk = 8, n_tail = 0, chunks = 1;
     if (const char* e = getenv("RT_TAIL_CHUNK")) { const int c = atoi(e); if (c >= 1) chunk = c; }   // (the two switches: tests and tools/tail_sweep.py)
     if (!scratch_dev && spp_count >= 2 * chunk) {
@@ -2029,7 +2030,9 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
         long long t = n_tiles <= 2 * waves ? n_tiles : (n_tiles / 2 < 4 * waves ? n_tiles / 2 : 4 * waves);
         if (const char* e = getenv("RT_TAIL_TILES")) { t = atoll(e); if (t > n_tiles) t = n_tiles; if (t < 0) t = 0; }
         const long long per_tile = (long long)spp_count * 64 * (long long)sizeof(float4);
-        const long long cap = (2ll << 30) / per_tile;
+        long long cap_mb = 4096;
+        if (const char* e = getenv("RT_TAIL_MAX_MB")) { cap_mb = atoll(e); if (cap_mb < 0) cap_mb = 0; if (cap_mb > 32768) cap_mb = 32768; }
+        const long long cap = (cap_mb << 20) / per_tile;
         if (t > cap) t = cap;
         chunks = (spp_count + chunk - 1) / chunk;
         if (t * chunks * 64 + (long long)(n_tiles - t) * 64 > 0x7fffff00ll) t = 0;   // the work counter is 32 bits wide
@@ -2037,7 +2040,12 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
         if (n_tail > 0 && size_t(n_tail * per_tile) > G().tail_bytes) {
             if (G().tail) HIP_OK(hipFree(G().tail));
             G().tail = nullptr; G().tail_bytes = 0;
-            HIP_OK(hipMalloc(&G().tail, size_t(n_tail * per_tile)));
+            // a device that is short of memory gets a smaller tail, in the end none: the frame is the same, only its last part slower
+            while (n_tail > 0 && hipMalloc(&G().tail, size_t(n_tail * per_tile)) != hipSuccess) {
+                (void)hipGetLastError();
+                G().tail = nullptr;
+                n_tail /= 2;
+            }
             G().tail_bytes = size_t(n_tail * per_tile);
         }
     }

@@ -32,9 +32,13 @@ for w in ("c3", "c2", "box", "c4", "c5"):
                       "fetch_size_kb_per_launch": round(c["FETCH_SIZE"]), "write_size_kb_per_launch": round(c["WRITE_SIZE"]),
                       "hbm_bytes_per_launch": int(round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)),
                       "algorithmic_bytes_per_launch": wl["W"] * wl["H"] * 16,
-                      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/prof.sh), summed over the launches / their number; "
-                              "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; source profiles/%s_c3_summary.txt. Writes = the float4 "
-                              "accumulator (132.7 MB) + counters; the path stack is in LDS at depth 8 except levels 6-7" % rnd}
+                      "tail_buffer_bytes": 16384 * wl["spp"] * 64 * 16,
+                      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/prof.sh), render_kernel + tail_sum_kernel, summed over "
+                              "the launches / their number; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; source profiles/%s_c3_summary.txt. "
+                              "Algorithmic = the float4 accumulator (132.7 MB). The rest is the colour buffer of the frame's tail (DESIGN.md 4.5b): 16384 tiles x 256 "
+                              "samples x 64 pixels x 16 B = 4.29 GB, written once by render_kernel in scattered 16-byte stores (7.2 GB of write traffic: partial "
+                              "lines) and read once by tail_sum_kernel; 12.2 GB per 0.40 s frame = 30 GB/s, 0.4 %% of HBM bandwidth, bought for 3 %% of "
+                              "frame time. With RT_TAIL_MAX_MB=0 the frame moves 158 MB (profiles/r2b_traffic.json)" % rnd}
 json.dump(pmc_all, open(os.path.join(ROOT, "profiles", f"{rnd}_pmc.json"), "w"), indent=1)
 if traffic:
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)

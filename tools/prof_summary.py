@@ -27,11 +27,14 @@ for p in ("pmc1", "pmc2", "pmc3", "pmc4"):
             disp[k].add(row["Dispatch_Id"])
         lines.append("== counters, summed over dispatches (%s)" % os.path.relpath(f, out))
         for k, d in acc.items():
-            if "render" not in k:
+            if "render" not in k and "tail_sum" not in k:
                 continue
             for c, v in sorted(d.items()):
                 lines.append("%-40s %-28s %.6g  (%d dispatches)" % (k, c, v, len(disp[k])))
-                js["counters_per_launch"][c] = v / max(len(disp[k]), 1)
+                if "render" in k:
+                    js["counters_per_launch"][c] = js["counters_per_launch"].get(c, 0.0) + v / max(len(disp[k]), 1)
+                elif c in ("FETCH_SIZE", "WRITE_SIZE"):   # the frame's second kernel (sums the tail's colours): its HBM traffic belongs to the frame
+                    js["counters_per_launch"][c] = js["counters_per_launch"].get(c, 0.0) + v / max(len(disp[k]), 1)
 open(os.path.join(out, "summary.txt"), "w").write("\n".join(lines) + "\n")
 json.dump(js, open(os.path.join(out, "pmc.json"), "w"), indent=1)
 print("\n".join(lines))
