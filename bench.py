@@ -280,7 +280,11 @@ def main():
                        "rays_per_frame": total_rays // max(args.steps, 1), "seed": seed},
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 4), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
-                         "kernel": "render_kernel", "kernel_ms": round(k_ms, 3), "flops_per_ray": fpr,
+                         "kernel": "render_kernel (kernel_ms includes tail_sum_kernel, which adds the colours of the frame's last part in "
+                                   "sample order: 0.2 % of the time, DESIGN.md 4.5b)",
+                         "kernel_ms": round(k_ms, 3), "flops_per_ray": fpr,
+                         "traffic_note": "the accumulator is 16 B per pixel; the rest of `traffic` is the colour buffer of the frame's tail, "
+                                         "written and read once (profiles/traffic.json): < 1 % of HBM bandwidth",
                          "accounting": "algorithmic (SURVEY 8d): closest-hit scans x primitives x flops of the reference's test; "
                                        "the box hierarchy and the packed filter answer most tests without evaluating them",
                          "accumulator_GBps": round(W * H * 16 / (k_ms * 1e-3) / 1e9, 3) if k_ms > 0 else None},
