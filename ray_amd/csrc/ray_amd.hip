@@ -701,7 +701,7 @@ __device__ __forceinline__ bool shade_bounce(const DevScene& sc, Ray& ray, const
 RT_DEV V3 unwind_step(float4 e, V3 L) {
     V3 w = v3(e.x, e.y, e.z);
     if (e.w == kSpecularMark) return w * L;                                  // calc.cpp:119-120
-    return v3(0.0f, 0.0f, 0.0f) + w * L / e.w;                               // calc.cpp:129-130 (emitted == 0)
+    return div3_zero_plus(w * L, e.w);                                       // calc.cpp:129-130: emitted (= 0) + attenuation * spdf * L / pdf
 }
 __device__ __forceinline__ V3 unwind_path(const PathStack& st, int level, V3 L) {
     while (level > 0) {

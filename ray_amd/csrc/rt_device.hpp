@@ -27,6 +27,41 @@ RT_DEV V3 operator*(V3 v, float f) { return v3(v.x * f, v.y * f, v.z * f); }
 RT_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
 RT_DEV V3 operator-(V3 v) { return v3(-v.x, -v.y, -v.z); }
 RT_DEV V3 operator/(V3 v, float d) { return v3(v.x / d, v.y / d, v.z / d); }
+// v / d (QVector3D / float, three IEEE divisions by one divisor) with the divisor's part of the work done once. hipcc's FP32
+// division on gfx950 is v_div_scale (x2), v_rcp, one Newton step on the reciprocal, the quotient, two residual corrections (the
+// last one as v_div_fmas) and v_div_fixup; when the divisor and the numerator are normal numbers whose exponents are less than
+// 96 apart, v_div_scale passes both through unscaled, v_div_fmas is a plain fma and v_div_fixup returns its first operand, so the
+// quotient is exactly the fma chain below. The guard keeps well inside that: divisor and non-zero numerators in [2^-40, 2^40]
+// (radiance and pdf values are O(1)); all three numerators zero is let through as well and gives +0 where IEEE gives a signed
+// zero - the one caller adds the quotient to +0 (calc.cpp:129, `emitted + ...` with emitted = 0), which erases the sign. NaN
+// numerators stay NaN (operands must be results of arithmetic, as the caller's are: a SIGNALING NaN would slip through the
+// max / min of the guard). Everything else takes `/`. tools/div_check.hip compares the chain with `/` on 2^32 operand pairs.
+RT_DEV bool div3_shared_ok(V3 n, float d) {
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(n.x), __builtin_fabsf(n.y)), __builtin_fabsf(n.z));
+    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(n.x), __builtin_fabsf(n.y)), __builtin_fabsf(n.z));
+    const bool d_ok = d >= 0x1p-40f && d <= 0x1p40f;
+    return d_ok && hi <= 0x1p40f && (lo >= 0x1p-40f || hi == 0.0f);
+}
+RT_DEV V3 div3_zero_plus(V3 n, float d) {
+#ifdef __HIP_DEVICE_COMPILE__
+    if (div3_shared_ok(n, d)) {
+        float r = __builtin_amdgcn_rcpf(d);
+        const float e = __builtin_fmaf(-d, r, 1.0f);
+        r = __builtin_fmaf(e, r, r);
+        float q[3] = {n.x * r, n.y * r, n.z * r};
+        const float nn[3] = {n.x, n.y, n.z};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float rem = __builtin_fmaf(-d, q[k], nn[k]);
+            q[k] = __builtin_fmaf(rem, r, q[k]);
+            rem = __builtin_fmaf(-d, q[k], nn[k]);
+            q[k] = __builtin_fmaf(rem, r, q[k]);
+        }
+        return V3{0.0f + q[0], 0.0f + q[1], 0.0f + q[2]};
+    }
+#endif
+    return V3{0.0f + n.x / d, 0.0f + n.y / d, 0.0f + n.z / d};
+}
 RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RT_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 RT_DEV float length_squared(V3 v) { return v.x * v.x + v.y * v.y + v.z * v.z; }
