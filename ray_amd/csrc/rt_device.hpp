@@ -32,15 +32,27 @@ RT_DEV V3 operator/(V3 v, float d) { return v3(v.x / d, v.y / d, v.z / d); }
 // last one as v_div_fmas) and v_div_fixup; when the divisor and the numerator are normal numbers whose exponents are less than
 // 96 apart, v_div_scale passes both through unscaled, v_div_fmas is a plain fma and v_div_fixup returns its first operand, so the
 // quotient is exactly the fma chain below. The guard keeps well inside that: divisor and non-zero numerators in [2^-40, 2^40]
-// (radiance and pdf values are O(1)); all three numerators zero is let through as well and gives +0 where IEEE gives a signed
-// zero - the one caller adds the quotient to +0 (calc.cpp:129, `emitted + ...` with emitted = 0), which erases the sign. NaN
-// numerators stay NaN (operands must be results of arithmetic, as the caller's are: a SIGNALING NaN would slip through the
-// max / min of the guard). Everything else takes `/`. tools/div_check.hip compares the chain with `/` on 2^32 operand pairs.
+// (radiance and pdf values are O(1)); a zero numerator is let through as well and gives +0 where IEEE gives a signed zero -
+// the one caller adds the quotient to +0 (calc.cpp:129, `emitted + ...` with emitted = 0), which erases the sign. A NaN
+// numerator stays NaN (operands must be results of arithmetic, as the caller's products and conversions are: a SIGNALING
+// NaN would slip through the max / min of the first test). Everything else (infinities, huge, tiny) takes `/`. tools/div_check.hip compares the chain with `/` on 2^32 operand pairs.
 RT_DEV bool div3_shared_ok(V3 n, float d) {
+    // the usual case first, four compares: no numerator is zero (or all three are), nothing is NaN or infinite
     const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(n.x), __builtin_fabsf(n.y)), __builtin_fabsf(n.z));
     const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(n.x), __builtin_fabsf(n.y)), __builtin_fabsf(n.z));
     const bool d_ok = d >= 0x1p-40f && d <= 0x1p40f;
-    return d_ok && hi <= 0x1p40f && (lo >= 0x1p-40f || hi == 0.0f);
+    bool ok = d_ok && hi <= 0x1p40f && (lo >= 0x1p-40f || hi == 0.0f);
+#ifdef __HIP_DEVICE_COMPILE__
+    if (__ballot(!ok) == 0ull) return true;      // (wave-uniform: the second test runs only for waves that need it)
+#endif
+    // colours with ONE zero channel are common too ((0.8, 0.8, 0) is the built-in scene's ground): on the bit patterns, sign
+    // shifted out, every numerator is 0 or in [2^-40, 2^40] (u - 1 wraps a zero to the top)
+    const uint32_t kLo = 0x2b800000u, kHi = 0x53800000u;      // 2^-40, 2^40
+    const uint32_t ux = __builtin_bit_cast(uint32_t, n.x) << 1, uy = __builtin_bit_cast(uint32_t, n.y) << 1, uz = __builtin_bit_cast(uint32_t, n.z) << 1;
+    const uint32_t top = ux > uy ? (ux > uz ? ux : uz) : (uy > uz ? uy : uz);
+    const uint32_t a = ux - 1u, b = uy - 1u, c = uz - 1u;
+    const uint32_t bottom = a < b ? (a < c ? a : c) : (b < c ? b : c);
+    return ok || (d_ok && top <= (kHi << 1) && bottom >= (kLo << 1) - 1u);
 }
 RT_DEV V3 div3_zero_plus(V3 n, float d) {
 #ifdef __HIP_DEVICE_COMPILE__
