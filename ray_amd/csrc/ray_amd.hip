@@ -498,7 +498,7 @@ __device__ __forceinline__ HitRec hit_record(const DevScene& sc, const Ray& r, c
     V3 outward;
     if (k == 0) {
         float4 s = sc.sph[j];
-        outward = (rec.p - v3(s.x, s.y, s.z)) / s.w;
+        outward = div3(rec.p - v3(s.x, s.y, s.z), s.w);     // (at - center) / radius, shapes.h:99
     } else if (k == 1) {
         int axis = sc.rect_axis[j];
         outward = axis == 0 ? v3(0, 0, 1) : (axis == 1 ? v3(0, 1, 0) : v3(1, 0, 0));

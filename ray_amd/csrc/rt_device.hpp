@@ -54,25 +54,41 @@ RT_DEV bool div3_shared_ok(V3 n, float d) {
     const uint32_t bottom = a < b ? (a < c ? a : c) : (b < c ? b : c);
     return ok || (d_ok && top <= (kHi << 1) && bottom >= (kLo << 1) - 1u);
 }
+#ifdef __HIP_DEVICE_COMPILE__
+RT_DEV V3 div3_chain(V3 n, float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q[3] = {n.x * r, n.y * r, n.z * r};
+    const float nn[3] = {n.x, n.y, n.z};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float rem = __builtin_fmaf(-d, q[k], nn[k]);
+        q[k] = __builtin_fmaf(rem, r, q[k]);
+        rem = __builtin_fmaf(-d, q[k], nn[k]);
+        q[k] = __builtin_fmaf(rem, r, q[k]);
+    }
+    return V3{q[0], q[1], q[2]};
+}
+#endif
+// (+0, +0, +0) + n / d
 RT_DEV V3 div3_zero_plus(V3 n, float d) {
 #ifdef __HIP_DEVICE_COMPILE__
     if (div3_shared_ok(n, d)) {
-        float r = __builtin_amdgcn_rcpf(d);
-        const float e = __builtin_fmaf(-d, r, 1.0f);
-        r = __builtin_fmaf(e, r, r);
-        float q[3] = {n.x * r, n.y * r, n.z * r};
-        const float nn[3] = {n.x, n.y, n.z};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float rem = __builtin_fmaf(-d, q[k], nn[k]);
-            q[k] = __builtin_fmaf(rem, r, q[k]);
-            rem = __builtin_fmaf(-d, q[k], nn[k]);
-            q[k] = __builtin_fmaf(rem, r, q[k]);
-        }
-        return V3{0.0f + q[0], 0.0f + q[1], 0.0f + q[2]};
+        const V3 q = div3_chain(n, d);
+        return V3{0.0f + q.x, 0.0f + q.y, 0.0f + q.z};
     }
 #endif
     return V3{0.0f + n.x / d, 0.0f + n.y / d, 0.0f + n.z / d};
+}
+// n / d, signed zeros included: the chain only when no numerator is zero (the first test of div3_shared_ok without its exception)
+RT_DEV V3 div3(V3 n, float d) {
+#ifdef __HIP_DEVICE_COMPILE__
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(n.x), __builtin_fabsf(n.y)), __builtin_fabsf(n.z));
+    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(n.x), __builtin_fabsf(n.y)), __builtin_fabsf(n.z));
+    if (d >= 0x1p-40f && d <= 0x1p40f && hi <= 0x1p40f && lo >= 0x1p-40f) return div3_chain(n, d);
+#endif
+    return V3{n.x / d, n.y / d, n.z / d};
 }
 RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RT_DEV V3 cross(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }

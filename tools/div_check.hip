@@ -34,7 +34,9 @@ __global__ void check(unsigned long long n, unsigned long long* bad, unsigned lo
         if ((h4 >> 24 & 3u) != 0u) d = __builtin_fabsf(d);                               // mostly positive, like a pdf
         const V3 got = div3_zero_plus(v, d);
         const V3 want = v3(0.0f + v.x / d, 0.0f + v.y / d, 0.0f + v.z / d);
-        if (!same(got.x, want.x) || !same(got.y, want.y) || !same(got.z, want.z)) {
+        const V3 got2 = div3(v, d);      // the form that keeps signed zeros
+        const bool bad2 = !same(got2.x, v.x / d) || !same(got2.y, v.y / d) || !same(got2.z, v.z / d);
+        if (bad2 || !same(got.x, want.x) || !same(got.y, want.y) || !same(got.z, want.z)) {
             ++nb;
             const unsigned long long slot = atomicAdd(bad + 2, 1ull);
             if (slot < 8) { float* e = ex + 10 * slot; e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = d; e[4] = got.x; e[5] = got.y; e[6] = got.z; e[7] = want.x; e[8] = want.y; e[9] = want.z; }
@@ -60,6 +62,6 @@ int main() {
         const float* e = ex + 10 * k;
         std::printf("  n = (%a, %a, %a) d = %a: got (%a, %a, %a) want (%a, %a, %a)\n", e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8], e[9]);
     }
-    std::printf("div3_zero_plus against IEEE division: %llu operand triples, %llu through the shared-reciprocal chain, %llu differing results\n", n, out[1], out[0]);
+    std::printf("div3_zero_plus and div3 against IEEE division: %llu operand triples, %llu through the shared-reciprocal chain, %llu differing results\n", n, out[1], out[0]);
     return out[0] != 0;
 }
