@@ -220,11 +220,7 @@ __device__ __forceinline__ uint32_t flag_rects(const DevScene& sc, const FilterR
 }
 constexpr int kRectFlagMin = 16;   // fewer rects: the direct loop of scan_rects
 
-#ifdef RT_EXPERIMENT_TRI_STAGED
-#define RT_WORDS_ALIGN __align__(16)   // the staging rows are read as float4
-#else
-#define RT_WORDS_ALIGN
-#endif
+#define RT_WORDS_ALIGN __align__(16)   // scan_triangles keeps 8-byte cells in it (the staged experiment reads rows as float4)
 // Triangle (not in the reference; DESIGN.md "triangles"): Moeller-Trumbore, FP32, NaN = miss.
 RT_DEV bool tri_t(const Ray& r, const float* __restrict__ q, double t_min, double bt, int idx, int bi, double* t_out) {
     V3 v0 = v3(q[0], q[1], q[2]), e1 = v3(q[3], q[4], q[5]), e2 = v3(q[6], q[7], q[8]);
@@ -315,7 +311,7 @@ __device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const R
 // triangles (every hit
 // point lies inside its triangle's sphere by definition of the primitive, ray_amd_tri.h), then
 // tri_t on the flagged pairs. h is exact on entry and on return.
-__device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r, double t_min, Hit& h, uint32_t* words RT_STAMP_PARAM) {
+__device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r, double t_min, Hit& h, uint32_t* words, bool& redo RT_STAMP_PARAM) {
     const FilterGroup& tg = sc.tg;
     if (tg.n_epairs == 0 && tg.n_fpairs == 0) return;
     auto visit = [&](int item) {       // an item: up to two triangles under one bounding sphere
@@ -336,18 +332,110 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     const unsigned long long here = __ballot(true);
     const int rank = int(__builtin_amdgcn_mbcnt_hi(uint32_t(here >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(here), 0u))), nact = __popcll(here);
 #endif
+#ifdef RT_EXPERIMENT_TRI_STAGED
     for (int fw0 = 0; fw0 < n_fwords; fw0 += kItemChunkWords) {
         if (!chunk_needed(tg, fr, __double2float_ru(h.t), fw0 / kItemChunkWords)) continue;
         const int nw = n_fwords - fw0 < kItemChunkWords ? n_fwords - fw0 : kItemChunkWords;
-#ifdef RT_EXPERIMENT_TRI_STAGED
         const uint32_t summary = filter_words_staged(tg, fr, __double2float_ru(h.t), fw0, nw, words, rank, nact RT_STAMP_ARG);
-#else
-        const uint32_t summary = filter_words<true>(tg, fr, __double2float_ru(h.t), fw0, nw, words RT_STAMP_ARG);
-#endif
         RT_STAMP(2);
         walk_flagged_items(summary, tg.n_ewords + fw0, words, visit RT_STAMP_ARG);
         RT_STAMP(3);
     }
+#else
+    // The flagged items of the wave's 64 rays go to ONE queue in the wave's part of the flag-word array (entries: item | owner lane)
+    // and the lanes share the triangle tests out evenly: a walk in which every lane tests its own items takes as many passes as
+    // the lane with most items needs - 19 passes per scan on the 9.8k-triangle frame for 2.4 items per lane, 12 % of the lanes on
+    // in 41 % of the frame's time. A worker lane fetches its entry's ray from the owner lane (ds_bpermute), tests the item's one
+    // or two triangles against the owner's t range, and folds a hit into the owner's cell with an LDS atomic min on the key
+    // (t, ~index): the order of tri_t's tie rule (equal t: the later primitive), so the cell ends up holding what the owner's
+    // own walk would have found, whatever the order of the tests. The owner then accepts it against its best hit as tri_t does.
+    // The queue is worked off when it is full, after a chunk once it holds a pass's worth (a hit found then prunes the chunks
+    // after it), and at the end. A hit at t == 0 (either sign: the key could not tell them apart) sends its ray to the list-order scan.
+    const int lane = int(threadIdx.x & 63);
+    uint32_t* wq = words - lane;                               // the wave's 64 columns: row k at wq + k * kScanBlock
+    constexpr int kQueueRows = kMaskWords - 2, kQueueCap = kQueueRows * 64;   // the last two rows hold the 64 cells
+    unsigned long long* const cells = reinterpret_cast<unsigned long long*>(wq + kQueueRows * kScanBlock);
+    auto cell_of = [&](int l) { return cells + (l >> 5) * (kScanBlock / 2) + (l & 31); };
+    constexpr unsigned long long kNoHit = ~0ull;
+    int q_len = 0;                                             // wave-uniform
+    const unsigned long long here = __ballot(true);            // (the loops below are wave-uniform: the set does not change)
+    const int rank_here = __popcll(here & ((1ull << lane) - 1ull)), n_here = __popcll(here);
+    auto walk_queue = [&]() {
+        if (q_len == 0) return;
+        *cell_of(lane) = kNoHit;
+        const float bt_f = __double2float_ru(h.t);
+        const float tmin_f = __double2float_rd(t_min);
+        asm volatile("" ::: "memory");                         // (LDS operations of one wave complete in order: only the compiler must keep it)
+        for (int base = 0; base < q_len; base += n_here) {    // the lanes that are in this scan share the entries out
+            RT_COUNT(0);
+            const int e = base + rank_here;
+            const bool work = e < q_len;
+            const uint32_t ent = work ? wq[(e >> 6) * kScanBlock + (e & 63)] : uint32_t(lane);
+            const int owner = int(ent & 63u), item = int(ent >> 6);
+            Ray rr;                                            // the owner's ray and t range (every lane of the scan takes part in the exchange)
+            rr.o = v3(__shfl(r.o.x, owner), __shfl(r.o.y, owner), __shfl(r.o.z, owner));
+            rr.d = v3(__shfl(r.d.x, owner), __shfl(r.d.y, owner), __shfl(r.d.z, owner));
+            rr.dl2 = 0.0f;
+            const float bt_o = __shfl(bt_f, owner), tmin_o = __shfl(tmin_f, owner);
+            if (work) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int slot = 2 * item + hh;
+                    const int idx = sc.tri_prim[slot];
+                    double t;
+                    if (idx >= 0 && tri_t(rr, sc.tri + 16 * slot, double(tmin_o), double(bt_o), idx, -1, &t)) {
+                        const float tf = float(t);             // exact: t is a widened float
+                        uint32_t tb = __float_as_uint(tf);
+                        tb = (tb & 0x80000000u) ? ~tb : (tb | 0x80000000u);                    // ordered like the floats
+                        unsigned long long key = ((unsigned long long)tb << 32) | (unsigned long long)(0xffffffffu - uint32_t(idx));
+                        if (tf == 0.0f) key = 0ull;
+                        atomicMin(cell_of(owner), key);
+                    }
+                }
+            }
+        }
+        asm volatile("" ::: "memory");
+        const unsigned long long k = *cell_of(lane);
+        if (k == 0ull) redo = true;
+        else if (k != kNoHit) {
+            uint32_t tb = uint32_t(k >> 32);
+            tb = (tb & 0x80000000u) ? (tb & 0x7fffffffu) : ~tb;
+            const double t = double(__uint_as_float(tb));
+            const int idx = int(0xffffffffu - uint32_t(k));
+            if (t >= t_min && t <= h.t && !(t == h.t && idx < h.prim)) { h.t = t; h.prim = idx; }   // tri_t's last test, against the exact range
+        }
+        q_len = 0;
+    };
+    for (int fw0 = 0; fw0 < n_fwords; fw0 += kItemChunkWords) {
+        if (!chunk_needed(tg, fr, __double2float_ru(h.t), fw0 / kItemChunkWords)) continue;
+        const int nw = n_fwords - fw0 < kItemChunkWords ? n_fwords - fw0 : kItemChunkWords;
+        filter_words_emit<true>(tg, fr, __double2float_ru(h.t), fw0, nw, [&](int wi, uint32_t f0, uint32_t f1) {
+            const int wbase = (tg.n_ewords + fw0 + wi) * 32;   // the word's first pair
+            uint32_t cur0 = f0, cur1 = f1;                     // item 0's flags of the word first, then item 1's
+            for (;;) {                                         // one entry per lane and pass
+                const bool has = (cur0 | cur1) != 0u;
+                const unsigned long long pushing = __ballot(has);
+                if (pushing == 0ull) break;
+                const int cnt = __popcll(pushing);
+                if (q_len + cnt > kQueueCap) { RT_STAMP(2); walk_queue(); RT_STAMP(3); }
+                if (has) {
+                    const bool second = cur0 == 0u;
+                    const uint32_t c = second ? cur1 : cur0;
+                    const int p = __builtin_clz(c);
+                    const uint32_t rest = c & ~(0x80000000u >> p);
+                    if (second) cur1 = rest; else cur0 = rest;
+                    const int slot = q_len + __popcll(pushing & ((1ull << lane) - 1ull));
+                    wq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(2 * (wbase + p) + (second ? 1 : 0)) << 6) | uint32_t(lane);
+                }
+                q_len += cnt;
+            }
+        } RT_STAMP_ARG);
+        RT_STAMP(2);
+        if (q_len >= kItemFlush) { walk_queue(); RT_STAMP(3); }
+    }
+    walk_queue();
+    RT_STAMP(3);
+#endif
 }
 
 // Triangles of one ray through the BVH (the acceleration structure the reference planned over its
@@ -477,7 +565,7 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
         if (!saw_nan && (sc.tg.n_epairs | sc.tg.n_fpairs) != 0) {
             const DevScene sc_tri = KARG ? load_kernarg<DevScene>(0) : sc;
             if (TRIS == 1 || (TRIS == 2 && sc.tbvh != nullptr)) scan_triangles_bvh(sc_tri, r, t_min, h, words);
-            else scan_triangles(sc_tri, r, t_min, h, words RT_STAMP_ARG);
+            else scan_triangles(sc_tri, r, t_min, h, words, saw_nan RT_STAMP_ARG);
         }
         ok = !saw_nan;
     }

@@ -42,6 +42,11 @@ constexpr int kItemChunkWords = 6, kStageWord = 12;
 #else
 constexpr int kItemChunkWords = 8;
 #endif
+// scan_triangles: the wave's queue of flagged items is worked off after a chunk once it holds this many entries (one pass's worth)
+#ifndef RT_ITEM_FLUSH
+#define RT_ITEM_FLUSH 64
+#endif
+constexpr int kItemFlush = RT_ITEM_FLUSH;
 // Filter margin factor: M = kMarginK * a * (S^2 + So^2 + r2max) with S = |o'| + cmax, So = |o - g| + cmax.
 // 96 * 2^-24, against a derived bound of < 64 * 2^-24.
 constexpr float kMarginK = 96.0f * 5.9604644775390625e-08f;
@@ -330,10 +335,10 @@ __device__ __forceinline__ bool chunk_needed(const FilterGroup& fg, const Filter
 // best t so far (boxes wholly beyond it are not needed).
 // ITEMS: one flag per ITEM instead (for kinds whose exact test is expensive per item: triangles): item 0's
 // flags of word wi at words[wi], item 1's at words[wi + kItemChunkWords]; nw <= kItemChunkWords.
-template <bool ITEMS = false>
-__device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const FilterRay& fr, float t_hi, int fw0, int nw, uint32_t* words RT_STAMP_PARAM) {
+// emit(wi, flags, flags1): called once per word wi that some lane of the wave needs, with this lane's flags (ITEMS: of item 0 and of item 1)
+template <bool ITEMS, class Emit>
+__device__ __forceinline__ void filter_words_emit(const FilterGroup& fg, const FilterRay& fr, float t_hi, int fw0, int nw, Emit&& emit RT_STAMP_PARAM) {
     cf2p fi = RT_CONST_F2(fg.fi);
-    uint32_t summary = 0;
     // level 0, words: the box around each word's 4 batches, two words per packed operation (fw0 is even)
     uint32_t wact = 0;                                     // wave-uniform: words that some lane needs
     for (int q = 0; 2 * q < nw; ++q) {
@@ -391,11 +396,18 @@ __device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const Fi
                 if (ITEMS) m1 |= nd[bb] ? 0u : 0xffu;
             }
         }
-        const uint32_t flagged = ITEMS ? ~(m & m1) : ~m;
-        words[wi * kScanBlock] = ~m;
-        if (ITEMS) words[(wi + kItemChunkWords) * kScanBlock] = ~m1;
-        summary |= (flagged != 0u ? 1u : 0u) << wi;
+        emit(wi, ~m, ~m1);
     }
+}
+template <bool ITEMS = false>
+__device__ __forceinline__ uint32_t filter_words(const FilterGroup& fg, const FilterRay& fr, float t_hi, int fw0, int nw, uint32_t* words RT_STAMP_PARAM) {
+    uint32_t summary = 0;
+    filter_words_emit<ITEMS>(fg, fr, t_hi, fw0, nw, [&](int wi, uint32_t f0, uint32_t f1) {
+        const uint32_t flagged = ITEMS ? (f0 | f1) : f0;
+        words[wi * kScanBlock] = f0;
+        if (ITEMS) words[(wi + kItemChunkWords) * kScanBlock] = f1;
+        summary |= (flagged != 0u ? 1u : 0u) << wi;
+    } RT_STAMP_ARG);
     return summary;
 }
 

@@ -1039,3 +1039,46 @@ def test_tail_units_give_the_same_frame(rt, monkeypatch):
     monkeypatch.delenv("RT_TAIL_CHUNK")
     rt.render(W, H, 15, depth, seed=77)
     assert rt.last_kernel_ms()[1] == 1
+
+
+def test_triangle_queue_overflow_negative_t_and_zero_t(rt):
+    """scan_triangles shares the flagged items of a wave's rays out among its lanes through a queue in LDS and folds hits into the
+    owner's cell with an atomic min on (t, ~index). Stress what the frames do not: rays through 20 stacked layers of a dense
+    mesh (hundreds of entries per wave: the queue fills up and is worked off in the middle of a chunk), a negative t_min (hits
+    behind the origin: keys of negative floats), origins exactly on a layer (t == 0: those rays take the list-order scan), a
+    ray count that leaves the last wave half empty, and ties between coplanar duplicates (the later primitive wins)."""
+    rng = np.random.default_rng(8)
+    mats = [scenes.Material(scenes.MAT_LAMBERTIAN, (0.5, 0.5, 0.5))]
+    shapes = []
+    n, layers = 10, 20
+    for L in range(layers):
+        z = np.float32(L) * np.float32(0.5)
+        for i in range(n):
+            for j in range(n):
+                a, b, c, d = (i, j, z), (i + 1, j, z), (i + 1, j + 1, z), (i, j + 1, z)
+                shapes.append(scenes.Shape("triangle", tuple(float(v) for v in (*a, *b, *c)), 0))
+                shapes.append(scenes.Shape("triangle", tuple(float(v) for v in (*a, *c, *d)), 0))
+    for k in range(30):            # duplicates of some triangles of layer 3: equal t, the later index must win
+        s = shapes[3 * 2 * n * n + 7 * k]
+        shapes.append(scenes.Shape("triangle", s.data, 0))
+    sc = scenes.Scene(mats, shapes, None, scenes.rayview_camera())
+    rt.upload_scene(sc, set_camera=False)
+    m = 64 * 37 + 29
+    ro = np.empty((m, 3), np.float32)
+    ro[:, 0] = rng.uniform(0.05, n - 0.05, m); ro[:, 1] = rng.uniform(0.05, n - 0.05, m)
+    zsel = rng.integers(0, 3, m)
+    ro[:, 2] = np.where(zsel == 0, -2.0, np.where(zsel == 1, rng.integers(0, layers, m) * 0.5, rng.uniform(-1, layers * 0.5, m))).astype(np.float32)
+    rd = np.empty((m, 3), np.float32)
+    rd[:, 0] = rng.uniform(-0.02, 0.02, m); rd[:, 1] = rng.uniform(-0.02, 0.02, m)
+    rd[:, 2] = np.where(rng.random(m) < 0.5, 1.0, -1.0) * rng.uniform(0.5, 2.0, m)
+    for t_min, t_max in ((1e-4, np.inf), (-100.0, np.inf), (-3.0, 2.5), (0.0, np.inf)):
+        got = rt.hit_rays(ro, rd, t_min, t_max)
+        ref = O.hit_rays(sc, ro, rd, t_min, t_max)
+        assert np.array_equal(got[0], ref[0]), (t_min, t_max)
+        assert O.bits_equal(got[1], ref[1]), (t_min, t_max)
+        assert (got[0] >= 0).mean() > 0.6
+    assert (ref[1][ref[0] >= 0] == 0).any()                       # the t == 0 path was taken
+    neg = rt.hit_rays(ro, rd, -100.0, np.inf)
+    assert (neg[1][neg[0] >= 0] < 0).mean() > 0.3                # and hits behind the origin are found
+    dup = rt.hit_rays(ro, rd, 1e-4, np.inf)[0]
+    assert (dup >= 2 * n * n * layers).any()                     # a duplicate (later index) won a tie
