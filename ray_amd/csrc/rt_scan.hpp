@@ -40,7 +40,10 @@ constexpr int kScanBlock = 256;                // threads per block of every ker
 // its staging rows for the filter data of one word's 4 batches (filter_words_staged)
 constexpr int kItemChunkWords = 6, kStageWord = 12;
 #else
-constexpr int kItemChunkWords = 8;
+#ifndef RT_ITEM_CHUNK_WORDS
+#define RT_ITEM_CHUNK_WORDS 8
+#endif
+constexpr int kItemChunkWords = RT_ITEM_CHUNK_WORDS;
 #endif
 // scan_triangles: the wave's queue of flagged items is worked off after a chunk once it holds this many entries (one pass's worth)
 #ifndef RT_ITEM_FLUSH
