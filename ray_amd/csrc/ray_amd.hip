@@ -406,8 +406,17 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
         }
         q_len = 0;
     };
+    const bool one_chunk = n_fwords <= kItemChunkWords;       // (chunk_needed's rule: a group of one chunk has no chunk boxes to test)
+    unsigned long long pair_needs[2] = {~0ull, ~0ull};
     for (int fw0 = 0; fw0 < n_fwords; fw0 += kItemChunkWords) {
-        if (!chunk_needed(tg, fr, __double2float_ru(h.t), fw0 / kItemChunkWords)) continue;
+        const int ci = fw0 / kItemChunkWords;
+        if (!one_chunk && (ci & 1) == 0) {                     // the chunk boxes come in pairs: one slab test decides two chunks
+            cf2p cb = RT_CONST_F2(tg.cbnd) + (ci >> 1) * 6;
+            bool n0, n1;
+            box_pair(fr, __double2float_ru(h.t), cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], n0, n1);
+            pair_needs[0] = __ballot(n0); pair_needs[1] = __ballot(n1);
+        }
+        if (pair_needs[ci & 1] == 0ull) continue;              // (the odd chunk's answer is from before the even chunk was searched: a superset)
         const int nw = n_fwords - fw0 < kItemChunkWords ? n_fwords - fw0 : kItemChunkWords;
         filter_words_emit<true>(tg, fr, __double2float_ru(h.t), fw0, nw, [&](int wi, uint32_t f0, uint32_t f1) {
             const int wbase = (tg.n_ewords + fw0 + wi) * 32;   // the word's first pair
