@@ -420,21 +420,24 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
         const int nw = n_fwords - fw0 < kItemChunkWords ? n_fwords - fw0 : kItemChunkWords;
         filter_words_emit<true>(tg, fr, __double2float_ru(h.t), fw0, nw, [&](int wi, uint32_t f0, uint32_t f1) {
             const int wbase = (tg.n_ewords + fw0 + wi) * 32;   // the word's first pair
-            uint32_t cur0 = f0, cur1 = f1;                     // item 0's flags of the word first, then item 1's
-            for (;;) {                                         // one entry per lane and pass
-                const bool has = (cur0 | cur1) != 0u;
-                const unsigned long long pushing = __ballot(has);
-                if (pushing == 0ull) break;
-                const int cnt = __popcll(pushing);
+            uint32_t cur0 = f0, cur1 = f1;
+            for (;;) {                                         // per pass and lane one entry for an item 0 and one for an item 1
+                const unsigned long long push0 = __ballot(cur0 != 0u), push1 = __ballot(cur1 != 0u);
+                if ((push0 | push1) == 0ull) break;
+                const int cnt0 = __popcll(push0), cnt = cnt0 + __popcll(push1);
                 if (q_len + cnt > kQueueCap) { RT_STAMP(2); walk_queue(); RT_STAMP(3); }
-                if (has) {
-                    const bool second = cur0 == 0u;
-                    const uint32_t c = second ? cur1 : cur0;
-                    const int p = __builtin_clz(c);
-                    const uint32_t rest = c & ~(0x80000000u >> p);
-                    if (second) cur1 = rest; else cur0 = rest;
-                    const int slot = q_len + __popcll(pushing & ((1ull << lane) - 1ull));
-                    wq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(2 * (wbase + p) + (second ? 1 : 0)) << 6) | uint32_t(lane);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (cur0 != 0u) {
+                    const int p = __builtin_clz(cur0);
+                    cur0 &= ~(0x80000000u >> p);
+                    const int slot = q_len + __popcll(push0 & below);
+                    wq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(2 * (wbase + p)) << 6) | uint32_t(lane);
+                }
+                if (cur1 != 0u) {
+                    const int p = __builtin_clz(cur1);
+                    cur1 &= ~(0x80000000u >> p);
+                    const int slot = q_len + cnt0 + __popcll(push1 & below);
+                    wq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(2 * (wbase + p) + 1) << 6) | uint32_t(lane);
                 }
                 q_len += cnt;
             }
