@@ -1787,6 +1787,8 @@ int rt_upload_scene(const RtScene* s) {
             ++i;
         }
         build_group(bound, r2k, kMarginKTri, finite, kItemChunkWords, tgb);
+        if (tgb.slot_item.size() >= (size_t(1) << 26))   // scan_triangles packs an item slot and a lane into 32 bits
+            return fail("rt_upload_scene: %zu triangle item slots exceed the limit of 2^26", tgb.slot_item.size());
 
         const float nanf_ = std::numeric_limits<float>::quiet_NaN();
         std::vector<float> tri2(tgb.slot_item.size() * 2 * 16, nanf_);   // two triangle slots per item slot
