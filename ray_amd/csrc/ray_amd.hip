@@ -353,7 +353,9 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     // after it), and at the end. A hit at t == 0 (either sign: the key could not tell them apart) sends its ray to the list-order scan.
     const int lane = int(threadIdx.x & 63);
     uint32_t* wq = words - lane;                               // the wave's 64 columns: row k at wq + k * kScanBlock
-    constexpr int kQueueRows = kMaskWords - 2, kQueueCap = kQueueRows * 64;   // the last two rows hold the 64 cells
+    constexpr int kBatchRows = 2;                              // rows 0, 1: the queue of (batch, owner) entries of the shared filter
+    constexpr int kQueueRows = kMaskWords - 2, kQueueCap = (kQueueRows - kBatchRows) * 64;   // the last two rows hold the 64 cells
+    uint32_t* const iq = wq + kBatchRows * kScanBlock;         // the item queue's first row
     unsigned long long* const cells = reinterpret_cast<unsigned long long*>(wq + kQueueRows * kScanBlock);
     auto cell_of = [&](int l) { return cells + (l >> 5) * (kScanBlock / 2) + (l & 31); };
     constexpr unsigned long long kNoHit = ~0ull;
@@ -370,7 +372,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
             RT_COUNT(0);
             const int e = base + rank_here;
             const bool work = e < q_len;
-            const uint32_t ent = work ? wq[(e >> 6) * kScanBlock + (e & 63)] : uint32_t(lane);
+            const uint32_t ent = work ? iq[(e >> 6) * kScanBlock + (e & 63)] : uint32_t(lane);
             const int owner = int(ent & 63u), item = int(ent >> 6);
             Ray rr;                                            // the owner's ray and t range (every lane of the scan takes part in the exchange)
             rr.o = v3(__shfl(r.o.x, owner), __shfl(r.o.y, owner), __shfl(r.o.z, owner));
@@ -406,47 +408,103 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
         }
         q_len = 0;
     };
-    const bool one_chunk = n_fwords <= kItemChunkWords;       // (chunk_needed's rule: a group of one chunk has no chunk boxes to test)
-    unsigned long long pair_needs[2] = {~0ull, ~0ull};
-    for (int fw0 = 0; fw0 < n_fwords; fw0 += kItemChunkWords) {
-        const int ci = fw0 / kItemChunkWords;
-        if (!one_chunk && (ci & 1) == 0) {                     // the chunk boxes come in pairs: one slab test decides two chunks
-            cf2p cb = RT_CONST_F2(tg.cbnd) + (ci >> 1) * 6;
-            bool n0, n1;
-            box_pair(fr, __double2float_ru(h.t), cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], n0, n1);
-            pair_needs[0] = __ballot(n0); pair_needs[1] = __ballot(n1);
-        }
-        if (pair_needs[ci & 1] == 0ull) continue;              // (the odd chunk's answer is from before the even chunk was searched: a superset)
-        const int nw = n_fwords - fw0 < kItemChunkWords ? n_fwords - fw0 : kItemChunkWords;
-        filter_words_emit<true>(tg, fr, __double2float_ru(h.t), fw0, nw, [&](int wi, uint32_t f0, uint32_t f1) {
-            const int wbase = (tg.n_ewords + fw0 + wi) * 32;   // the word's first pair
-            uint32_t cur0 = f0, cur1 = f1;
-            for (;;) {                                         // per pass and lane one entry for an item 0 and one for an item 1
+    // Level 1 is shared out the same way. The wave-uniform filter runs every batch that SOME lane needs for all 64 lanes (18.9
+    // batches per scan on the 9.8k-triangle frame where a lane needs 3). Level 0 says per lane which batches it needs: (batch,
+    // owner) entries go to a second queue (one ballot per batch, no per-lane loop), and every lane filters ONE entry's 8 pairs
+    // for the entry's owner - the batch's 256 bytes through vector loads instead of SGPR operands, the owner's nine filter
+    // constants through ds_bpermute, the same packed FMAs - and pushes the flagged items to the item queue under the owner's name.
+    constexpr int kBatchCap = kBatchRows * 64;
+    int bq_len = 0;
+    auto filter_batches = [&]() {
+        for (int base = 0; base < bq_len; base += n_here) {
+            const int e = base + rank_here;
+            const bool work = e < bq_len;
+            const uint32_t ent = work ? wq[(e >> 6) * kScanBlock + (e & 63)] : uint32_t(lane);
+            const int owner = int(ent & 63u), batch = int(ent >> 6);
+            const f2 D01 = {__shfl(fr.D01.x, owner), __shfl(fr.D01.y, owner)}, D2O = {__shfl(fr.D2O.x, owner), __shfl(fr.D2O.y, owner)};
+            const f2 NAM = {__shfl(fr.NAM.x, owner), __shfl(fr.NAM.y, owner)}, W01 = {__shfl(fr.W01.x, owner), __shfl(fr.W01.y, owner)};
+            const f2 W2 = {__shfl(fr.W2.x, owner), 0.0f};
+            uint32_t m = 0u, m1 = 0u;                           // bit set: item 0 / item 1 of pair jj (bit 7 - jj) NOT flagged
+            if (work) {
+                const float4* __restrict__ bd = reinterpret_cast<const float4*>(tg.fi) + size_t(batch) * 16;
+#pragma unroll 2
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float4 A = bd[2 * jj], B = bd[2 * jj + 1];
+                    const f2 X = {A.x, A.y}, Y = {A.z, A.w}, Z = {B.x, B.y}, K = {B.z, B.w};
+                    f2 bq = pk_fma_cc_v<0, 1>(D01, X, D2O);
+                    bq = pk_fma_cv_v<1>(D01, Y, bq);
+                    bq = pk_fma_cv_v<0>(D2O, Z, bq);
+                    f2 Q = pk_fma_cc_v<0, 1>(NAM, K, NAM);
+                    Q = pk_fma_cv_v<0>(W01, X, Q);
+                    Q = pk_fma_cv_v<1>(W01, Y, Q);
+                    Q = pk_fma_cv_v<0>(W2, Z, Q);
+                    const f2 T = __builtin_elementwise_fma(bq, bq, Q);   // >= 0 (sign bit clear): flagged
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x), 31);
+                    m1 = __builtin_amdgcn_alignbit(m1, __float_as_uint(T.y), 31);
+                }
+            }
+            uint32_t cur0 = work ? (~m & 0xffu) : 0u, cur1 = work ? (~m1 & 0xffu) : 0u;   // bit 7 - jj: pair jj of the batch
+            const int pbase = tg.n_ewords * 32 + batch * 8;
+            for (;;) {
                 const unsigned long long push0 = __ballot(cur0 != 0u), push1 = __ballot(cur1 != 0u);
                 if ((push0 | push1) == 0ull) break;
                 const int cnt0 = __popcll(push0), cnt = cnt0 + __popcll(push1);
-                if (q_len + cnt > kQueueCap) { RT_STAMP(2); walk_queue(); RT_STAMP(3); }
+                if (q_len + cnt > kQueueCap) walk_queue();
                 const unsigned long long below = (1ull << lane) - 1ull;
                 if (cur0 != 0u) {
-                    const int p = __builtin_clz(cur0);
-                    cur0 &= ~(0x80000000u >> p);
+                    const int p = __builtin_clz(cur0) - 24;
+                    cur0 &= ~(0x80u >> p);
                     const int slot = q_len + __popcll(push0 & below);
-                    wq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(2 * (wbase + p)) << 6) | uint32_t(lane);
+                    iq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(2 * (pbase + p)) << 6) | uint32_t(owner);
                 }
                 if (cur1 != 0u) {
-                    const int p = __builtin_clz(cur1);
-                    cur1 &= ~(0x80000000u >> p);
+                    const int p = __builtin_clz(cur1) - 24;
+                    cur1 &= ~(0x80u >> p);
                     const int slot = q_len + cnt0 + __popcll(push1 & below);
-                    wq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(2 * (wbase + p) + 1) << 6) | uint32_t(lane);
+                    iq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(2 * (pbase + p) + 1) << 6) | uint32_t(owner);
                 }
                 q_len += cnt;
             }
-        } RT_STAMP_ARG);
+        }
+        bq_len = 0;
+    };
+    {
+        const bool one_chunk_s = n_fwords <= kItemChunkWords;
+        unsigned long long pair_needs_s[2] = {~0ull, ~0ull};
+        for (int fw0 = 0; fw0 < n_fwords; fw0 += kItemChunkWords) {
+            const int ci = fw0 / kItemChunkWords;
+            if (!one_chunk_s && (ci & 1) == 0) {
+                cf2p cb = RT_CONST_F2(tg.cbnd) + (ci >> 1) * 6;
+                bool n0, n1;
+                box_pair(fr, __double2float_ru(h.t), cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], n0, n1);
+                pair_needs_s[0] = __ballot(n0); pair_needs_s[1] = __ballot(n1);
+            }
+            if (pair_needs_s[ci & 1] == 0ull) continue;
+            const int nw = n_fwords - fw0 < kItemChunkWords ? n_fwords - fw0 : kItemChunkWords;
+            filter_words_level0(tg, fr, __double2float_ru(h.t), fw0, nw, [&](int fw, const bool (&nd)[4], int real) {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    const bool need = nd[bb] && bb < real;
+                    const unsigned long long pushing = __ballot(need);
+                    if (pushing == 0ull) continue;
+                    const int cnt = __popcll(pushing);
+                    if (bq_len + cnt > kBatchCap) filter_batches();
+                    if (need) {
+                        const int slot = bq_len + __popcll(pushing & ((1ull << lane) - 1ull));
+                        wq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(fw * 4 + bb) << 6) | uint32_t(lane);
+                    }
+                    bq_len += cnt;
+                }
+            });
+            RT_STAMP(2);
+            if (bq_len >= 64) { filter_batches(); RT_STAMP(2); }
+            if (q_len >= kItemFlush) { walk_queue(); RT_STAMP(3); }
+        }
+        filter_batches();
         RT_STAMP(2);
-        if (q_len >= kItemFlush) { walk_queue(); RT_STAMP(3); }
+        walk_queue();
+        RT_STAMP(3);
     }
-    walk_queue();
-    RT_STAMP(3);
 #endif
 }
 

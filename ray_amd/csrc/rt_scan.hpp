@@ -303,7 +303,6 @@ __device__ __forceinline__ f2 pk_fma_cc_v(f2 c, f2 x, f2 a) {
     else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(c), "v"(x), "v"(a));
     return r;
 }
-#ifdef RT_EXPERIMENT_TRI_STAGED
 template <int SC>
 __device__ __forceinline__ f2 pk_fma_cv_v(f2 c, f2 x, f2 a) {
     f2 r;
@@ -311,7 +310,6 @@ __device__ __forceinline__ f2 pk_fma_cv_v(f2 c, f2 x, f2 a) {
     else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(c), "v"(x), "v"(a));
     return r;
 }
-#endif
 __device__ __forceinline__ void box_pair_v(const FilterRay& fr, float t_hi, f2 CX, f2 CY, f2 CZ, f2 EX, f2 EY, f2 EZ, bool& n0, bool& n1, float& e0,
                                            float& e1) {
     const f2 ux = pk_fma_cc_v<0, 0>(fr.I01, CX, fr.KX), wx = pk_fma_cc_v<0, 1>(fr.A01, EX, fr.KX);
@@ -338,6 +336,29 @@ __device__ __forceinline__ bool chunk_needed(const FilterGroup& fg, const Filter
 // best t so far (boxes wholly beyond it are not needed).
 // ITEMS: one flag per ITEM instead (for kinds whose exact test is expensive per item: triangles): item 0's
 // flags of word wi at words[wi], item 1's at words[wi + kItemChunkWords]; nw <= kItemChunkWords.
+// Level 0 only, for filter words [fw0, fw0 + nw): on_word(fw, nd, real) is called for every word that some lane of the wave needs,
+// with this lane's answer per batch (nd[bb]: the lane needs batch bb of the word) and the number of real batches of the word.
+template <class OnWord>
+__device__ __forceinline__ void filter_words_level0(const FilterGroup& fg, const FilterRay& fr, float t_hi, int fw0, int nw, OnWord&& on_word) {
+    uint32_t wact = 0;                                     // wave-uniform: words that some lane needs
+    for (int q = 0; 2 * q < nw; ++q) {
+        cf2p wb = RT_CONST_F2(fg.wbnd) + (fw0 / 2 + q) * 6;
+        bool n0, n1;
+        box_pair(fr, t_hi, wb[0], wb[1], wb[2], wb[3], wb[4], wb[5], n0, n1);
+        wact |= (__ballot(n0) != 0ull ? 1u : 0u) << (2 * q);
+        wact |= (__ballot(n1) != 0ull && 2 * q + 1 < nw ? 1u : 0u) << (2 * q + 1);
+    }
+    for (int wi = 0; wi < nw; ++wi) {
+        const int fw = fw0 + wi;
+        cf2p bn = RT_CONST_F2(fg.bnd) + fw * 12;
+        if ((wact >> wi & 1u) == 0u) continue;
+        bool nd[4];
+        box_pair(fr, t_hi, bn[0], bn[2], bn[4], bn[6], bn[8], bn[10], nd[0], nd[1]);
+        box_pair(fr, t_hi, bn[1], bn[3], bn[5], bn[7], bn[9], bn[11], nd[2], nd[3]);
+        on_word(fw, nd, fg.n_fbatches - fw * 4);
+    }
+}
+
 // emit(wi, flags, flags1): called once per word wi that some lane of the wave needs, with this lane's flags (ITEMS: of item 0 and of item 1)
 template <bool ITEMS, class Emit>
 __device__ __forceinline__ void filter_words_emit(const FilterGroup& fg, const FilterRay& fr, float t_hi, int fw0, int nw, Emit&& emit RT_STAMP_PARAM) {
