@@ -653,6 +653,7 @@ __device__ __forceinline__ void scan_spheres(const FilterGroup& sg, const int* _
 #endif
     const FilterRay fr = filter_ray(sg, o, d, a, ia, t_min);
     const int n_fwords = sg.n_fpairs >> 5;
+#ifdef RT_SPHERES_WAVE_UNIFORM_FILTER
     for (int fw0 = 0; fw0 < n_fwords; fw0 += kMaskWords) {
         const int nw = n_fwords - fw0 < kMaskWords ? n_fwords - fw0 : kMaskWords;
         const uint32_t summary = filter_words(sg, fr, h.bhi, fw0, nw, words RT_STAMP_ARG);
@@ -660,6 +661,83 @@ __device__ __forceinline__ void scan_spheres(const FilterGroup& sg, const int* _
         walk_flagged(summary, sg.n_ewords + fw0, words, visit RT_STAMP_ARG);
         RT_STAMP(3);
     }
+#else
+    // Level 1 shared out among the lanes (as scan_triangles does): the wave-uniform filter runs every batch that
+    // SOME lane needs for all 64 lanes (6.9 batches per scan on the 485-sphere frame where a lane needs 2). Level 0 says per lane
+    // which batches it needs; (batch, owner) entries go to a queue in rows 14, 15 of the wave's part of the flag-word array, and
+    // every lane filters ONE entry's 8 pairs for its owner (the batch's 256 bytes through vector loads, the owner's nine filter
+    // constants through ds_bpermute, the same packed FMAs) and writes the 8 flags as one BYTE of the owner's flag word (a batch
+    // is a byte of its word) plus the word's bit of the owner's summary (row 12). Chunks of 12 words; the owner's walk is as before.
+    constexpr int kChunk = 12, kSumRow = 12, kQueueRow = 14, kQueueCap = 128;
+    const int lane = int(threadIdx.x & 63);
+    uint32_t* wq = words - lane;                               // the wave's 64 columns: row k at wq + k * kScanBlock
+    const unsigned long long here = __ballot(true);            // (the loops below are wave-uniform: the set does not change)
+    const int rank_here = __popcll(here & ((1ull << lane) - 1ull)), n_here = __popcll(here);
+    for (int fw0 = 0; fw0 < n_fwords; fw0 += kChunk) {
+        const int nw = n_fwords - fw0 < kChunk ? n_fwords - fw0 : kChunk;
+        for (int wi = 0; wi < nw; ++wi) words[wi * kScanBlock] = 0u;
+        words[kSumRow * kScanBlock] = 0u;
+        int bq_len = 0;                                        // wave-uniform
+        auto filter_batches = [&]() {
+            asm volatile("" ::: "memory");                     // (LDS operations of one wave complete in order: only the compiler must keep it)
+            for (int base = 0; base < bq_len; base += n_here) {
+                const int e = base + rank_here;
+                const bool work = e < bq_len;
+                const uint32_t ent = work ? wq[(kQueueRow + (e >> 6)) * kScanBlock + (e & 63)] : uint32_t(lane);
+                const int owner = int(ent & 63u), lb = int(ent >> 6);          // lb: batch of the chunk, 4 per word
+                const f2 D01 = {__shfl(fr.D01.x, owner), __shfl(fr.D01.y, owner)}, D2O = {__shfl(fr.D2O.x, owner), __shfl(fr.D2O.y, owner)};
+                const f2 NAM = {__shfl(fr.NAM.x, owner), __shfl(fr.NAM.y, owner)}, W01 = {__shfl(fr.W01.x, owner), __shfl(fr.W01.y, owner)};
+                const f2 W2 = {__shfl(fr.W2.x, owner), 0.0f};
+                if (work) {
+                    const float4* __restrict__ bd = reinterpret_cast<const float4*>(sg.fi) + size_t(fw0 * 4 + lb) * 16;
+                    uint32_t m = 0u;                           // bit set: pair jj (bit 7 - jj) NOT flagged
+#pragma unroll 2
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const float4 A = bd[2 * jj], B = bd[2 * jj + 1];
+                        const f2 X = {A.x, A.y}, Y = {A.z, A.w}, Z = {B.x, B.y}, K = {B.z, B.w};
+                        f2 bq = pk_fma_cc_v<0, 1>(D01, X, D2O);
+                        bq = pk_fma_cv_v<1>(D01, Y, bq);
+                        bq = pk_fma_cv_v<0>(D2O, Z, bq);
+                        f2 Q = pk_fma_cc_v<0, 1>(NAM, K, NAM);
+                        Q = pk_fma_cv_v<0>(W01, X, Q);
+                        Q = pk_fma_cv_v<1>(W01, Y, Q);
+                        Q = pk_fma_cv_v<0>(W2, Z, Q);
+                        const f2 T = __builtin_elementwise_fma(bq, bq, Q);   // >= 0 (sign bit clear): flagged
+                        m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x) & __float_as_uint(T.y), 31);
+                    }
+                    const uint32_t fb = ~m & 0xffu;
+                    if (fb != 0u) {
+                        const int wi = lb >> 2, bb = lb & 3;
+                        reinterpret_cast<uint8_t*>(wq + wi * kScanBlock + owner)[3 - bb] = uint8_t(fb);   // pairs 8 bb .. 8 bb + 7 <-> bits 31 - 8 bb ..
+                        atomicOr(wq + kSumRow * kScanBlock + owner, 1u << wi);
+                    }
+                }
+            }
+            bq_len = 0;
+        };
+        filter_words_level0(sg, fr, h.bhi, fw0, nw, [&](int fw, const bool (&nd)[4], int real) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const bool need = nd[bb] && bb < real;
+                const unsigned long long pushing = __ballot(need);
+                if (pushing == 0ull) continue;
+                const int cnt = __popcll(pushing);
+                if (bq_len + cnt > kQueueCap) filter_batches();
+                if (need) {
+                    const int slot = bq_len + __popcll(pushing & ((1ull << lane) - 1ull));
+                    wq[(kQueueRow + (slot >> 6)) * kScanBlock + (slot & 63)] = (uint32_t((fw - fw0) * 4 + bb) << 6) | uint32_t(lane);
+                }
+                bq_len += cnt;
+            }
+        });
+        filter_batches();
+        asm volatile("" ::: "memory");
+        const uint32_t summary = words[kSumRow * kScanBlock];
+        RT_STAMP(2);
+        walk_flagged(summary, sg.n_ewords + fw0, words, visit RT_STAMP_ARG);
+        RT_STAMP(3);
+    }
+#endif
     if (h.dD >= 0.0f) { resolve_exact(a, t_min, t_max, h, false, 0.0f, 0.0f, -1); }
     RT_STAMP(3);
 }
