@@ -427,7 +427,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
             uint32_t m = 0u, m1 = 0u;                           // bit set: item 0 / item 1 of pair jj (bit 7 - jj) NOT flagged
             if (work) {
                 const float4* __restrict__ bd = reinterpret_cast<const float4*>(tg.fi) + size_t(batch) * 16;
-#pragma unroll 2
+#pragma unroll RT_SHARE_UNROLL
                 for (int jj = 0; jj < 8; ++jj) {
                     const float4 A = bd[2 * jj], B = bd[2 * jj + 1];
                     const f2 X = {A.x, A.y}, Y = {A.z, A.w}, Z = {B.x, B.y}, K = {B.z, B.w};

@@ -31,6 +31,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef const f2 __attribute__((address_space(4)))* cf2p;
 #define RT_CONST_F2(p) ((rt::cf2p)(uintptr_t)(p))
 
+#ifndef RT_SHARE_UNROLL
+#define RT_SHARE_UNROLL 8          // pairs per trip of the shared filter's loop over a batch (more: more loads in flight, more VGPRs)
+#endif
 constexpr int kMaskWords = 16;                 // flag words per lane and chunk (32 pairs each), kept in LDS
 constexpr int kScanBlock = 256;                // threads per block of every kernel that scans
 // Groups with one flag per ITEM (triangles): chunks of kItemChunkWords filter words, item 0's flags in the first kItemChunkWords
@@ -691,7 +694,7 @@ __device__ __forceinline__ void scan_spheres(const FilterGroup& sg, const int* _
                 if (work) {
                     const float4* __restrict__ bd = reinterpret_cast<const float4*>(sg.fi) + size_t(fw0 * 4 + lb) * 16;
                     uint32_t m = 0u;                           // bit set: pair jj (bit 7 - jj) NOT flagged
-#pragma unroll 2
+#pragma unroll RT_SHARE_UNROLL
                     for (int jj = 0; jj < 8; ++jj) {
                         const float4 A = bd[2 * jj], B = bd[2 * jj + 1];
                         const f2 X = {A.x, A.y}, Y = {A.z, A.w}, Z = {B.x, B.y}, K = {B.z, B.w};
