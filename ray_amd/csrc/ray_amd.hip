@@ -1239,7 +1239,7 @@ __global__ __launch_bounds__(kBlock) void hit_rays_kernel(DevScene sc, long long
     }
 }
 
-__global__ __launch_bounds__(kBlock) void trace_rays_kernel(DevScene sc, long long n, const float* __restrict__ ro,
+__global__ __launch_bounds__(kBlock, 4) void trace_rays_kernel(DevScene sc, long long n, const float* __restrict__ ro,
                                                             const float* __restrict__ rd, int depth, uint64_t seed, uint32_t flags,
                                                             float* __restrict__ rgb, float4* __restrict__ stack) {
     __shared__ RT_WORDS_ALIGN uint32_t s_words[kMaskWords * kBlock];
