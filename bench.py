@@ -155,6 +155,54 @@ def quick_run(ctx, api, scenes, torch, dev, name, frames=1):
             "Mrays_per_s": round(n / dt / 1e6, 1), "rays_per_frame": n // frames}
 
 
+XGMI_LINK_GBPS = 153.0   # one xGMI link of an MI355X (7 per GPU); a ring collective is bound by one link
+
+
+def shares_run(ctx, scenes, torch, dev, frames=3):
+    """The one-GPU bound on the 8-GPU curve. No node with more than one GPU is available to the builder, so
+    the scaling curve itself cannot be measured; what CAN be measured on one GPU is the time rank 0 of a G-rank job spends in its
+    render call: for the spp-split (c3) samples [0, spp / G) of every pixel, for the tile-split (c5) the interleaved bands 0, G,
+    2G, ... at full spp. With the exchange ESTIMATED (ring over one xGMI link: all-reduce 2 (G-1)/G S / B, all-gather (G-1)/G S /
+    B, S = the 132.7 MB accumulator, B = 153 GB/s) the efficiency of G ranks cannot exceed
+    t_full / (G (t_share + t_exchange_est)): a CEILING (load imbalance between ranks and RCCL's real time come on top)."""
+    out = {}
+    for name, kind in (("c3", "spp"), ("c5", "tile")):
+        wl = WORKLOADS[name]
+        W, H, spp, depth = wl["W"], wl["H"], wl["spp"], wl["depth"]
+        ctx.upload_scene(scenes.get_scene(wl["scene"], **wl["kw"]))
+        acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+        bytes_acc = W * H * 16
+
+        def timed(G, n):
+            kw = dict(spp_begin=0) if kind == "spp" else dict(band_first=0, band_stride=G)
+            s = spp // G if kind == "spp" else spp
+            ctx.render_into(W, H, acc, min(s, 8), depth, seed=0xC0FFEE, **kw)      # warm-up of this shape
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            k_ms = 0.0
+            for _ in range(n):
+                ctx.render_into(W, H, acc, s, depth, seed=0xC0FFEE, **kw)
+                k_ms += ctx.last_kernel_ms()[0]
+            torch.cuda.synchronize(dev)
+            return 1e3 * (time.perf_counter() - t0) / n, k_ms / n
+
+        n_full = 1 if name == "c5" else frames
+        t_full, k_full = timed(1, n_full)
+        rows = {}
+        for G in (2, 4, 8):
+            t, k = timed(G, frames if name == "c3" else 1)
+            ex = ((2.0 if kind == "spp" else 1.0) * (G - 1) / G * bytes_acc / (XGMI_LINK_GBPS * 1e9)) * 1e3
+            rows[str(G)] = {"t_share_ms": round(t, 3), "kernel_ms": round(k, 3), "G_t_share_over_t_full": round(G * t / t_full, 4),
+                            "t_exchange_est_ms": round(ex, 3), "efficiency_ceiling": round(t_full / (G * (t + ex)), 4)}
+        out[name] = {"workload": wl["desc"], "split": kind, "t_full_ms": round(t_full, 3), "kernel_full_ms": round(k_full, 3), "ranks": rows}
+        del acc
+    out["note"] = ("one GPU: the render call of rank 0 of a G-rank job (c3: samples [0, spp/G) of every pixel; c5: bands 0, G, 2G, ... at "
+                   "full spp), wall clock per call incl. launch and sync; exchange ESTIMATED as a ring over one 153 GB/s xGMI link on the "
+                   "132.7 MB accumulator (all-reduce 2(G-1)/G S/B, all-gather (G-1)/G S/B); efficiency_ceiling = t_full / (G (t_share + "
+                   "t_exchange_est)) is an upper bound, NOT a measured scaling curve")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,6 +212,7 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (diagnostics only)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the short runs of the other workloads (the `also` dict)")
+    ap.add_argument("--no-shares", action="store_true", help="skip the per-rank share timings (also.shares)")
     args = ap.parse_args()
 
     import torch
@@ -301,6 +350,8 @@ def main():
             # the other single-GPU workloads, one timed frame each, so that 1080p (BASELINE.json configs[1]) and the triangle
             # configs are driver-observed as well; their rocprof summaries are profiles/r2_<name>_*
             out["also"] = {n: quick_run(ctx, api, scenes, torch, dev, n) for n in ("c2", "box", "c4", "c5") if n != args.workload}
+            if not args.no_shares:
+                out["also"]["shares"] = shares_run(ctx, scenes, torch, dev)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(scene, wl)
         print(json.dumps(out), flush=True)

@@ -97,6 +97,11 @@ typedef struct RtCamera {
 #define RT_RENDER_NOWAIT 8u     /* rt_render / rt_render_bands / rt_render_noalloc return as soon as  */
                                 /* the kernel is queued; rt_sync() (or the next call on the context)  */
                                 /* waits for it. Lets ONE host thread keep several GPUs busy.          */
+#define RT_RENDER_CONTINUE 16u  /* rt_render / rt_render_bands / rt_render_noalloc: every pixel's sum goes on   */
+                                /* from d_accum's contents IN SAMPLE ORDER, ((acc + c_s) + c_s+1) + ..., .w += */
+                                /* spp_count: calls over consecutive sample ranges leave bit for bit what ONE  */
+                                /* call over the whole range leaves, i.e. renderOneRay's in-order sum          */
+                                /* (rayview.cpp:79-84). (ACCUMULATE adds the pass's own sum: acc + (c_s + ...).) */
 
 /* ---- context ------------------------------------------------------------------------------------ */
 /* Bind this process to HIP device `device` and create the library's stream. Fails (no CPU
@@ -112,6 +117,25 @@ int rt_set_device(int device);
  * instead of the library's own; rt_reset_stream() goes back to the library's. See "stream ordering" above.  */
 int rt_set_stream(void* hip_stream);
 int rt_reset_stream(void);
+/* How rt_render / rt_render_bands / rt_render_noalloc cut a pixel's samples into the units of work their kernel hands out
+ * (no counterpart in the reference, whose unit is a whole pixel on one thread, rayview.cpp:67-87). A pixel's samples
+ * are rendered as consecutive SLICES whose sizes halve down to min_samples (default 8): large units while the frame is
+ * in full swing, small ones at its end so that no lane waits long for another's last pixel; a slice continues the
+ * pixel's sum in sample order from the accumulator, so every setting gives the same bits as whole pixels do.
+ * min_samples = 0: whole pixels only. max_slices: at most that many slices per call (1..16, default 16).
+ * Device memory this needs: 4 bytes per 8x8 tile of the frame (grown on demand, freed by rt_shutdown).                 */
+int rt_set_sample_slices(int min_samples, int max_slices);
+/* Upper limit (MiB; default 2048, 0 = none) of the colour buffer that rt_render / rt_render_bands keep for the END of a
+ * frame (no counterpart in the reference). Up to half of a frame's tiles (all of them on small frames) are rendered last, in units of 8 samples per pixel whose colours (16 bytes each: 1 KiB per tile and
+ * sample) go to this buffer and are added in sample order by a second kernel: the same bits as a pixel summed by one
+ * thread, but parallel over a pixel's samples too, which is what keeps every lane fed while the frame runs out. The buffer
+ * is allocated by the first frame that wants it, grown on demand up to the limit, and released by this call (when it
+ * holds more than the new limit), by rt_upload_scene and by rt_shutdown; a device that cannot spare it gets a smaller
+ * one or none. Where the limit leaves less than half the buffer a frame would like (1 KiB x tiles x samples: 4K frames of
+ * hundreds of samples), the other tiles are rendered in sample slices (rt_set_sample_slices) instead of as whole pixels.
+ * Frames are bit-identical whatever the limit; only their last part is slower with less (4K / 256 spp on MI355X: 381 ms
+ * with 4 GiB, 385 with 2, 390 with 1 or none; 1080p / 64 spp frames want 1 GiB).                                   */
+int rt_set_tail_limit(int64_t megabytes);
 /* Destroys the calling thread's current context.                                                           */
 void rt_shutdown(void);
 const char* rt_last_error(void);
@@ -164,11 +188,9 @@ int rt_hit_rays(int64_t n, const float* d_origin, const float* d_dir, double t_m
  * the number of closest-hit scans executed (primary + bounce rays), added atomically.
  * Pixels outside [y_begin, y_begin + y_count) are not touched (image-tile split).
  * Device memory the call keeps in the context (grown on demand, freed by rt_shutdown): the path stack beyond
- * six bounces, and, for spp_count >= 16, a colour buffer for the end of the frame: the last part of a frame is
- * rendered in units of 8 samples per pixel whose colours (16 bytes each) a second kernel adds in sample order -
- * the same bits as a pixel summed by one thread, without the idle lanes of a frame that ends pixel by pixel.
- * Its size is 64 KiB x spp_count / 64 per 8x8 tile for up to half the frame's tiles, at most 4 GiB (environment
- * RT_TAIL_MAX_MB; 0 = none); a device that cannot spare it gets a smaller one or none, with the same result.      */
+ * six bounces (16 bytes x (depth - 6) per resident thread), 4 bytes per 8x8 tile of the frame for the order
+ * between a pixel's sample slices (rt_set_sample_slices), and for spp_count >= 16 the colour buffer of the frame's
+ * end, at most 2 GiB unless rt_set_tail_limit says otherwise.                                                  */
 int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth,
               uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
 
@@ -176,9 +198,10 @@ int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_cou
  * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc. Same arguments, same
  * kernels and bit-identical results as rt_render, but the kernel's scratch (the tile counter and the HBM part
  * of the per-thread path stack, which rt_render keeps in buffers it allocates and grows on demand) lives in a
- * file-scope device array of the library: 40 MiB + 256 B on every GPU the library is bound to, held until the
- * process ends. The call makes no hipMalloc / hipFree and calls no allocating routine (so it also renders the
- * end of the frame as whole pixels, without rt_render's colour buffer: same result, a slower last part).
+ * file-scope device array of the library: 44 MiB + 256 B on every GPU the library is bound to, held until the
+ * process ends. The call makes no hipMalloc / hipFree and calls no allocating routine (so it renders without
+ * rt_render's colour buffer for the end of the frame: same result, a slower last part). The array also holds the
+ * per-tile words of the sample slices for frames of up to 2^20 tiles (67 Mpixel; larger frames: whole pixels).
  * Limits: depth <= 16 (RT_NOALLOC_MAX_DEPTH; deeper paths are rejected with an error, use rt_render);
  * RT_RENDER_VERIFY is rejected. Every call on one GPU shares that GPU's array: calls that overlap in time on
  * one GPU race (the library issues them on one stream, so calls from one host thread never do).             */

@@ -15,6 +15,7 @@ RENDER_ACCUMULATE = 1
 RENDER_NORMALS = 2
 RENDER_VERIFY = 4
 RENDER_NOWAIT = 8
+RENDER_CONTINUE = 16
 
 
 class RtError(RuntimeError):
@@ -68,10 +69,40 @@ def _dev_ptr(x) -> Optional[int]:
     return int(x)
 
 
+class _BoundLib:
+    """The C library as one Context object sees it. The library keeps one context per GPU and every entry point acts on the
+    calling thread's CURRENT one (include/ray_amd.h), so with two Context objects in a process each call must first make
+    its own object's context current: every function fetched from here does rt_set_device(device) before the call."""
+
+    _UNBOUND = ("rt_init", "rt_set_device", "rt_last_error", "rt_device_count", "rt_camera_from_lookat")
+
+    def __init__(self, lib, device: int):
+        self._lib, self._device = lib, device
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name in self._UNBOUND:
+            return fn
+        lib, device = self._lib, self._device
+
+        def bound(*args):
+            if lib.rt_set_device(device) != 0:
+                raise RtError(lib.rt_last_error().decode())
+            return fn(*args)
+        bound.__name__ = name
+        setattr(self, name, bound)      # (argtypes of diagnostic entries are set on the raw library: see raw())
+        return bound
+
+    def raw(self):
+        return self._lib
+
+
 class Context:
     def __init__(self, device: int = 0, lib_path: str = capi.LIB_PATH):
-        self.lib = capi.load_library(lib_path)
-        self._check(self.lib.rt_init(device))
+        raw = capi.load_library(lib_path)
+        if raw.rt_init(device) != 0:
+            raise RtError(raw.rt_last_error().decode())
+        self.lib = _BoundLib(raw, device)
         self.device = device
         self._scene_keep = None
 
@@ -101,8 +132,16 @@ class Context:
     def sync(self):
         self._check(self.lib.rt_sync())
 
+    def set_sample_slices(self, min_samples: int = 8, max_slices: int = 16):
+        """rt_set_sample_slices: how a pixel's samples are cut into units of work (0 = whole pixels); same bits either way."""
+        self._check(self.lib.rt_set_sample_slices(min_samples, max_slices))
+
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
+
+    def set_tail_limit(self, megabytes: int = 2048):
+        """rt_set_tail_limit: upper limit of the colour buffer for the end of a frame (0 = none); same bits either way."""
+        self._check(self.lib.rt_set_tail_limit(megabytes))
 
     # ---- scene / camera --------------------------------------------------------------------------
     def upload_scene(self, scene, set_camera: bool = True):
@@ -221,8 +260,9 @@ class Context:
 
 class Progressive:
     """RayView::go (rayview.cpp:98-117) for the GPU: each go() is one time slice of full-frame passes that
-    ACCUMULATE into one device accumulator; sample indices continue across slices, reset() (scene or
-    camera changed) starts again from sample 0. Mirrors ProgressiveView of ray_amd/host/ray_amd_host.h."""
+    CONTINUE one device accumulator in sample order (RT_RENDER_CONTINUE: after n samples it holds what one call of n
+    samples leaves, bit for bit); sample indices continue across slices, reset() (scene or camera changed) starts
+    again from sample 0. Mirrors ProgressiveView of ray_amd/host/ray_amd_host.h."""
 
     def __init__(self, ctx: Context, W: int, H: int, depth: int, seed: int = 0):
         self.ctx, self.W, self.H, self.depth, self.seed = ctx, W, H, depth, seed
@@ -237,7 +277,7 @@ class Progressive:
     def go(self, budget_ms: float = 16.0) -> int:
         used = 0.0
         while True:
-            flags = RENDER_ACCUMULATE if self.done else 0
+            flags = RENDER_CONTINUE if self.done else 0
             self.ctx.render_into(self.W, self.H, self.acc, self.per_pass, self.depth, seed=self.seed, flags=flags, spp_begin=self.done)
             ms, _ = self.ctx.last_kernel_ms()
             self.done += self.per_pass

@@ -74,6 +74,8 @@ _PROTOS = {
     "rt_set_device": ([C.c_int], C.c_int),
     "rt_set_stream": ([C.c_void_p], C.c_int),
     "rt_reset_stream": ([], C.c_int),
+    "rt_set_sample_slices": ([C.c_int, C.c_int], C.c_int),
+    "rt_set_tail_limit": ([C.c_int64], C.c_int),
     "rt_shutdown": ([], None),
     "rt_last_error": ([], C.c_char_p),
     "rt_device_info": ([C.c_char_p, C.c_int], C.c_int),

@@ -898,7 +898,8 @@ __device__ __forceinline__ V3 trace_path(const DevScene& sc, Ray ray, Rng& g, in
 // ================================================================================================
 constexpr int kBlock = kScanBlock;   // 4 waves
 constexpr int kTile = 8;             // work unit handed to a wave: one 8x8 pixel tile
-constexpr uint32_t kNoTail = 0xffffffffu;
+constexpr long long kMaxWorkItems = 0x70000000ll;   // the work counter is a 32-bit int; the rest is room for every resident wave's last fetch
+constexpr int kMaxSlices = 16;        // sample slices per pixel and call (render_kernel)
 
 struct RenderArgs {
     int W, H, y_begin, y_count, spp_begin, spp_count, depth;
@@ -914,12 +915,18 @@ struct RenderArgs {
     const int* __restrict__ pixels;                // PIXELS kernels: [n_pixels] pixel indices y * W + x to render
     int n_pixels;
     double inv_w, inv_h;                           // 1 / double(float(W)), 1 / double(float(H)), correctly rounded (host): see jitter_div
-    // The end of the frame in finer units (render_kernel "tail"): n_tail_tiles tiles, every tail_stride-th of the frame (tile
-    // tt * tail_stride + tail_stride - 1), are handed out after the other n_bulk_tiles, as tail_chunks units of tail_chunk samples
-    // per pixel whose colours go to `tail` and are summed in sample order by tail_sum_kernel. n_tail_tiles = 0: no tail (the
-    // PIXELS kernels, rt_render_noalloc, frames of few samples).
-    int n_bulk_tiles, n_tail_tiles, tail_chunk, tail_chunks, tail_stride;
+    // Sample slices (render_kernel "slices"): the samples [spp_begin, spp_begin + spp_count) of a pixel are cut into n_slices
+    // consecutive slices, slice k = [spp_begin + slice_begin[k], spp_begin + slice_begin[k + 1]); the units of work are (slice, tile)
+    // pairs. n_slices = 1: whole pixels (the PIXELS kernels, RT_RENDER_ACCUMULATE, frames of few samples).
+    int n_tiles, n_slices;
+    int slice_begin[kMaxSlices + 1];
+    // The tail: n_tail_tiles tiles, every tail_stride-th of the frame (tile tt * tail_stride + tail_stride - 1), are not among the n_tiles
+    // above. They come after all of those, as tail_chunks units of tail_chunk samples per pixel whose colours go to `tail` and are
+    // summed in sample order by tail_sum_kernel: work that is parallel over a pixel's samples too, for the end of the frame.
+    int n_tail_tiles, tail_chunk, tail_chunks, tail_stride;
     float4* __restrict__ tail;                     // [n_tail_tiles][spp_count][64] colour of sample s of pixel `in` of tail tile t
+    unsigned int* __restrict__ tile_state;         // [n_tiles] low byte: slices of the tile that are finished; bit 8 + k: unit (k, tile) came up before
+                                                   // slice k - 1 was finished and belongs to whoever finishes it (zeroed before the launch; null when n_slices == 1)
 };
 
 // (x + xi) / float(W) of rayview.cpp:80-81 without the FP32 division sequence: float(double(n) * inv) with inv = RN(1 / double(float(W))).
@@ -936,6 +943,17 @@ RT_DEV float jitter_div(float n, float w, double inv) {
     return n / w;
 #endif
 }
+
+// 16 bytes written through to memory (sc1): visible to every XCD once the store has completed (s_waitcnt vmcnt(0)), without a release fence.
+// The compiler does not count a store inside an asm statement; the kernel waits for it explicitly before it publishes the unit
+// (render_kernel, complete_unit), and an uncounted store in flight only makes the compiler's own vmcnt waits longer, never shorter.
+__device__ __forceinline__ void store_float4_sc1(float4* p, float4 v) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
+}
+constexpr uint32_t kTailSlot = 4u;   // render_kernel: the `slot` of a lane that renders a pixel of a tail unit
+constexpr uint32_t kUnitTileBits = 26, kUnitTileMask = (1u << kUnitTileBits) - 1u;   // a unit as one word: slice << 26 | tile
 
 // The render kernel's arguments as they lie in the kernarg segment. Values that one section of the main loop needs are read from
 // there (scalar loads through the constant address space) where they are used, behind a pointer the compiler cannot see through:
@@ -957,13 +975,34 @@ static_assert(offsetof(RenderKernArgs, sc) == 0, "closest_hit<..., KARG> reads t
 // refilled with one 8x8 tile from a global counter (one atomic per wave and tile).
 // PIXELS: the work items are the entries of a caller-supplied pixel list (RayView::renderOneRay's random
 // pixels, rayview.cpp:69-70) instead of the tiles of a row range.
-// The tail. A lane's unit of work is a whole pixel, so a frame ends with every lane finishing the pixel it happens to hold: for
-// about one pixel's time lanes run dry one by one, waves over cheap pixels leave, and a 1080p frame of 64 samples (8 pixels
-// per lane in all) spends 10 - 20 % of its time that way (tools/tail_probe.py). The frame's last tiles are therefore handed
-// out in units of a few SAMPLES per pixel: a lane renders samples [s, s_end) of its pixel and stores each colour to ra.tail
-// instead of adding it up; tail_sum_kernel then adds a pixel's colours in sample order, exactly as the lane would have
-// (rayview.cpp:79-84 sums in order). The colour of a sample depends on (seed, pixel, sample) only, so the frame is bit-identical.
-template <bool VERIFY, bool PIXELS = false, int RECTS = 0, int MEDIA = 0, int TRIS = 0>
+// Sample slices. A lane's unit of work used to be a whole pixel, so a frame ended with every lane finishing the pixel it happened
+// to hold: for about one pixel's time lanes ran dry one by one (10 - 20 % of a 1080p frame of 64 samples, and 38 % of the 1/8 band
+// share of a 4K frame of 1024 samples, where a tile is 100 ms of a wave's time and a wave gets four). Now the samples of a pixel
+// are cut into slices (ra.slice_begin: each half of what is left, the last ones 8 samples) and the units of work are (slice, tile)
+// pairs. A lane that takes a pixel of slice k > 0 CONTINUES the pixel's sum: it starts from the accumulator's contents (the sum
+// of slices 0 .. k - 1, written by whichever lanes rendered them) and adds its own samples in sample order, so the pixel's sum is
+// the same chain of additions ((c0 + c1) + c2) + ... as one lane walking all samples (rayview.cpp:79-84), and the frame is
+// bit-identical to the whole-pixel one: a sample's colour depends on (seed, pixel, sample) only.
+// Order between the slices of a tile, without anybody ever waiting. The counter hands the units out slice by slice in tile order
+// (all tiles' slice 0, then all tiles' slice 1, ...: the pixels a wave holds stay neighbours, which keeps the union of what its
+// lanes need in a scan small). All 64 pixels of a unit are taken by lanes of the ONE wave that got it, so "the unit is done" is
+// wave-local bookkeeping on ballots (up to four unfinished units per wave, a byte each in left_word), no atomics per pixel.
+// tile_state[tile] holds the number of finished slices of the tile. A wave that gets unit (k, tile), k > 0, from the counter
+// ORs bit 8 + k into that word (one returning atomic): if the count it reads back is k the unit is ready and the wave renders
+// it; if not it has thereby LEFT the unit to whoever finishes slice k - 1, and takes the next unit from the counter. The wave that
+// finishes (k - 1, tile) adds 1 to the word (one returning atomic) and, if it reads bit 8 + k back, renders (k, tile) itself, before
+// anything else from the counter (its pixels are that tile's anyway). Both are atomics on one word, so exactly one of the two
+// sees the other: no unit is lost, none is rendered twice, nobody polls or spins, every wave exits when the counter has run out
+// and its own units are done. The XCDs' L2 caches are not coherent and a CU's L1 is never refreshed by another CU's stores, so the
+// hand-off follows the write-through recipe: the pixel-slices are stored with 16-byte sc1 stores (no release fence, which would
+// write back the whole L2, 2 - 6 us), the finishing wave waits for all its stores (s_waitcnt vmcnt(0)) before its atomic add;
+// the wave that takes the unit over does ONE agent-scope acquire (invalidates its CU's L1) before its lanes load the tile's pixels.
+// RT_RENDER_CONTINUE does the same across calls: slice 0 then also starts from the accumulator.
+#ifdef RT_STAMPS
+__device__ unsigned long long g_wave_times[8192][2];
+#endif
+// CHAIN: false = the launcher knows that every pixel is rendered as one slice (n_slices == 1): the slices' bookkeeping is compiled out
+template <bool VERIFY, bool PIXELS = false, int RECTS = 0, int MEDIA = 0, int TRIS = 0, bool CHAIN = true>
 __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra_entry) {
     __shared__ RT_WORDS_ALIGN uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
@@ -975,51 +1014,111 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
     bool have = false, path = false;
     int x = 0, y = 0, s = 0, s_end = 0, level = 0, depth_left = 0;
     uint32_t pix = 0, n_rays = 0;
-    uint32_t tail_at = kNoTail;    // tail units: index into ra.tail of this lane's pixel at sample spp_begin (kNoTail: a whole pixel, summed here)
+    float wn = 0.0f;               // the accumulator's .w (samples summed so far) of this lane's pixel
+    uint32_t slot = 0u;            // which of the wave's unfinished units this lane's pixel belongs to
     V3 sum = v3(0.0f, 0.0f, 0.0f);
     Ray ray = make_ray(v3(0, 0, 0), v3(0, 0, 0));
     Rng g; g.state = 0;
     int q_cur = 0, q_end = 0;      // wave-uniform: the wave's queue of work indices (one unit of 64 at a time), and what the unit is:
     int q_x0 = 0, q_y0 = 0, q_s0 = 0, q_s1 = 0;   // its tile's first pixel, its samples [q_s0, q_s1)
-    uint32_t q_at = kNoTail;                      // tail units: index into ra.tail of the tile's first pixel at sample spp_begin
-    bool exhausted = false;        // wave-uniform: the global counter has run past the last tile
+    uint32_t q_slot = 0u;          // the slot of the unit being handed out (kTailSlot: a tail unit, whose colours go to ra.tail at q_at)
+    uint32_t q_at = 0u;
+    uint32_t mine = 0u;            // bit u: slot u's unit is finished and the tile's NEXT slice (left to this wave by the wave that got it from the
+                                   // counter too early) has still to be begun; uid[u] already names it
+    // the wave's unfinished units: slot u's pixels still to finish in byte u of left_word (0: the slot is free), what it is in uid[u]
+    uint32_t left_word = 0u, uid0 = 0u, uid1 = 0u, uid2 = 0u, uid3 = 0u;
+    bool exhausted = false;        // wave-uniform: the global counter has run past the last unit
 #ifdef RT_STAMPS
     Stamps stp{};
     stp.last = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_wave_start = stp.last;
 #endif
 
     for (;;) {
+        bool finished = false;     // this lane's pixel-slice ended in this trip
         // ---- hand pixels to idle lanes ------------------------------------------------------------
         for (;;) {
             const unsigned long long need = __ballot(!have);
             if (need == 0ull) break;
             const RenderArgs ra = load_kernarg<RenderArgs>(offsetof(RenderKernArgs, ra));   // (every section reads its arguments where it uses them)
-            const int bulk_items = PIXELS ? ra.n_pixels : ra.n_bulk_tiles * 64;
-            const int total = PIXELS ? ra.n_pixels : bulk_items + ra.n_tail_tiles * ra.tail_chunks * 64;
+            const bool chained = CHAIN && !PIXELS && ra.n_slices > 1;
+            // a unit of tiles: its samples, its tile, a slot for the wave's bookkeeping
+            auto begin_unit = [&](int k, int tile) {
+                const int tiles_x = (ra.W + kTile - 1) / kTile;
+                // (indexed through the kernarg pointer: an index into the struct's copy would put the array in scratch memory)
+                const size_t sb = offsetof(RenderKernArgs, ra) + offsetof(RenderArgs, slice_begin) + size_t(k) * sizeof(int);
+                q_s0 = ra.spp_begin + load_kernarg<int>(sb); q_s1 = ra.spp_begin + load_kernarg<int>(sb + sizeof(int));
+                // the b-th tile that is not a tail tile
+                const int ftile = tile < ra.n_tail_tiles * (ra.tail_stride - 1) ? tile + tile / (ra.tail_stride - 1) : tile + ra.n_tail_tiles;
+                const int trow = ftile / tiles_x, tcol = ftile - trow * tiles_x;
+                q_x0 = tcol * kTile;
+                q_y0 = ra.y_begin + (ra.band_first + trow * ra.band_stride) * kTile;
+                q_cur = 0; q_end = 64; q_slot = 0u;
+#ifndef RT_EXP_NOSYNC
+                if (chained)
+#else
+                if (false)
+#endif
+                {
+                    const int nx = ra.W - q_x0 < kTile ? ra.W - q_x0 : kTile;
+                    const int ny = ra.y_begin + ra.y_count - q_y0 < kTile ? ra.y_begin + ra.y_count - q_y0 : kTile;
+                    // a free slot: no pixel of it unfinished, and not kept for an inherited unit that has still to be begun
+                    const uint32_t busy = ((left_word & 0xffu) != 0u ? 1u : 0u) | ((left_word & 0xff00u) != 0u ? 2u : 0u) |
+                                          ((left_word & 0xff0000u) != 0u ? 4u : 0u) | ((left_word & 0xff000000u) != 0u ? 8u : 0u) | mine;
+                    q_slot = uint32_t(__builtin_ctz(~busy));
+                    left_word |= uint32_t(nx * ny) << (8u * q_slot);
+                    const uint32_t id = (uint32_t(k) << kUnitTileBits) | uint32_t(tile);
+                    uid0 = q_slot == 0u ? id : uid0; uid1 = q_slot == 1u ? id : uid1; uid2 = q_slot == 2u ? id : uid2; uid3 = q_slot == 3u ? id : uid3;
+                }
+            };
             if (q_cur >= q_end) {
-                if (exhausted) break;
-                int base = 0;
-                if (lane == 0) base = int(atomicAdd(ra.work_counter, 64u));
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= total) { exhausted = true; break; }
-                q_cur = base; q_end = base + 64;
-                if (!PIXELS) {   // what the unit is: once per unit, on wave-uniform values
-                    const int tiles_x = (ra.W + kTile - 1) / kTile;
-                    int tile;
-                    q_s0 = ra.spp_begin; q_s1 = ra.spp_begin + ra.spp_count; q_at = kNoTail;
-                    if (base < bulk_items) {   // a whole tile: the b-th tile that is not a tail tile
-                        const int b = base >> 6;
-                        tile = b < ra.n_tail_tiles * (ra.tail_stride - 1) ? b + b / (ra.tail_stride - 1) : b + ra.n_tail_tiles;
-                    } else {                   // tail_chunk samples of tail tile tt = every tail_stride-th tile of the frame
-                        const int unit = (base - bulk_items) >> 6;
-                        const int tt = unit / ra.tail_chunks, ch = unit - tt * ra.tail_chunks;
-                        tile = tt * ra.tail_stride + ra.tail_stride - 1;
-                        q_s0 += ch * ra.tail_chunk;
-                        q_s1 = q_s0 + ra.tail_chunk < q_s1 ? q_s0 + ra.tail_chunk : q_s1;
-                        q_at = uint32_t(tt) * uint32_t(ra.spp_count) * 64u;
+                if (chained && mine == 0u && (left_word & 0xffu) != 0u && (left_word & 0xff00u) != 0u && (left_word & 0xff0000u) != 0u && (left_word & 0xff000000u) != 0u)
+                { RT_EVENT(1); break; }                              // four units of this wave are unfinished: their lanes go on, the idle ones wait
+                if (!PIXELS && mine != 0u) {                         // a unit this wave inherited by finishing the slice before it
+                    const uint32_t u = uint32_t(__builtin_ctz(mine));
+                    mine &= mine - 1u;
+                    const uint32_t id = u == 0u ? uid0 : (u == 1u ? uid1 : (u == 2u ? uid2 : uid3));
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // (its pixels were written through by this wave; L1 is not trusted)
+                    begin_unit(int(id >> kUnitTileBits), int(id & kUnitTileMask));
+                } else {
+                    if (exhausted) break;
+                    const int bulk_units = ra.n_tiles * ra.n_slices;
+                    const int total = PIXELS ? ra.n_pixels : (bulk_units + ra.n_tail_tiles * ra.tail_chunks) * 64;
+                    int base = 0;
+                    if (lane == 0) base = int(atomicAdd(ra.work_counter, 64u));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= total) { exhausted = true; break; }
+                    if (PIXELS) { q_cur = base; q_end = base + 64; }
+                    else {
+                        const int unit = base >> 6;
+                        if (unit >= bulk_units) {   // tail_chunk samples of tail tile tt = every tail_stride-th tile of the frame
+                            const int tu = unit - bulk_units;
+                            const int tt = tu / ra.tail_chunks, ch = tu - tt * ra.tail_chunks;
+                            const int tiles_x = (ra.W + kTile - 1) / kTile;
+                            const int ftile = tt * ra.tail_stride + ra.tail_stride - 1;
+                            const int trow = ftile / tiles_x, tcol = ftile - trow * tiles_x;
+                            q_x0 = tcol * kTile;
+                            q_y0 = ra.y_begin + (ra.band_first + trow * ra.band_stride) * kTile;
+                            q_s0 = ra.spp_begin + ch * ra.tail_chunk;
+                            q_s1 = q_s0 + ra.tail_chunk < ra.spp_begin + ra.spp_count ? q_s0 + ra.tail_chunk : ra.spp_begin + ra.spp_count;
+                            q_at = uint32_t(tt) * uint32_t(ra.spp_count) * 64u;
+                            q_cur = 0; q_end = 64; q_slot = kTailSlot;
+                            continue;
+                        }
+                        const int k = unit / ra.n_tiles, tile = unit - k * ra.n_tiles;   // (the units come slice by slice)
+#ifdef RT_EXP_NOSYNC
+                        if (false) {   // timing experiment only: WRONG frames (no order between a pixel's slices)
+#else
+                        if (k > 0) {
+#endif
+                            uint32_t old = 0u;
+                            if (lane == 0) old = atomicOr(ra.tile_state + tile, 1u << (8 + k));
+                            old = uint32_t(__builtin_amdgcn_readfirstlane(int(old)));
+                            if (int(old & 0xffu) < k) { RT_EVENT(7); continue; }   // not ready: left to whoever finishes the slice before it
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 may hold the tile's lines as they were slices ago
+                        }
+                        begin_unit(k, tile);
                     }
-                    q_x0 = (tile % tiles_x) * kTile;
-                    q_y0 = ra.y_begin + (ra.band_first + (tile / tiles_x) * ra.band_stride) * kTile;
                 }
             }
             const int rank = __popcll(need & ((1ull << lane) - 1ull));
@@ -1028,7 +1127,7 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
                 const int idx = q_cur + rank;
                 bool inside;
                 if (PIXELS) {
-                    inside = idx < total;
+                    inside = idx < ra.n_pixels;
                     const int p = inside ? ra.pixels[idx] : 0;
                     inside = inside && uint32_t(p) < uint32_t(ra.W) * uint32_t(ra.H);   // an index outside the frame is skipped, never written
                     y = p / ra.W; x = p - y * ra.W;
@@ -1043,8 +1142,16 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
                     pix = uint32_t(y) * uint32_t(ra.W) + uint32_t(x);
                     s = PIXELS ? ra.spp_begin : q_s0;
                     s_end = PIXELS ? ra.spp_begin + ra.spp_count : q_s1;
-                    tail_at = PIXELS || q_at == kNoTail ? kNoTail : q_at + uint32_t(idx & 63);
+                    slot = q_slot;
                     sum = v3(0.0f, 0.0f, 0.0f);
+                    wn = 0.0f;
+                    if (!PIXELS && q_slot == kTailSlot) {
+                        wn = __uint_as_float(q_at + uint32_t(idx & 63));   // (a tail pixel keeps no sums: the register holds its place in ra.tail)
+                    } else if (!PIXELS && !(q_s0 == ra.spp_begin && (ra.flags & RT_RENDER_CONTINUE) == 0u)) {   // continue the pixel's sum where the slice before left it. No
+                        const float4 o = ra.accum[pix];              // arithmetic on the loaded values here: their first use is the end
+                        sum = v3(o.x, o.y, o.z);                     // of the lane's first sample, so nobody waits for this load (the
+                        wn = o.w;                                    // line comes from HBM: the slice before wrote it through)
+                    }
                 }
             }
             const int want = __popcll(need);
@@ -1084,33 +1191,78 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
             RT_STAMP(5);
             if (done) {
                 const V3 colour = unwind_path(st, level, L);
-                const bool whole = PIXELS || tail_at == kNoTail;
-                if (whole) sum = sum + colour;                                // rayview.cpp:83
-                else ra.tail[tail_at + uint32_t(s - ra.spp_begin) * 64u] = make_float4(colour.x, colour.y, colour.z, 0.0f);
+                const bool tail_px = !PIXELS && slot == kTailSlot;
+                if (tail_px) {
+                    ra.tail[__float_as_uint(wn) + uint32_t(s - ra.spp_begin) * 64u] = make_float4(colour.x, colour.y, colour.z, 0.0f);
+                } else {
+                    sum = sum + colour;                                           // rayview.cpp:83
+                    wn += 1.0f;                                                   // (samples summed: exact up to 2^24)
+                }
                 path = false;
                 ++s;
-                if (s == s_end && !whole) have = false;
-                if (s == s_end && whole) {
-                    float4 a = make_float4(sum.x, sum.y, sum.z, float(ra.spp_count));
+                if (s == s_end && tail_px) have = false;
+                if (s == s_end && !tail_px) {
+                    float4 a = make_float4(sum.x, sum.y, sum.z, wn);
                     if (PIXELS && (ra.flags & RT_RENDER_ACCUMULATE)) {
                         // a pixel may be listed more than once (the reference draws its pixels at random, rayview.cpp:69-70):
                         // every listing adds its (identical) sums with one IEEE add each, in whatever order
                         float* q = reinterpret_cast<float*>(ra.accum + pix);
                         atomicAdd(q, a.x); atomicAdd(q + 1, a.y); atomicAdd(q + 2, a.z); atomicAdd(q + 3, a.w);
                     } else {
-                        if (ra.flags & RT_RENDER_ACCUMULATE) {
+                        if (ra.flags & RT_RENDER_ACCUMULATE) {                    // (one slice: the pass's own sum is added to what was there)
                             float4 o = ra.accum[pix];
                             a = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + float(ra.spp_count));
                         }
-                        ra.accum[pix] = a;
+#ifdef RT_EXP_NOSYNC   // (tools/: timing experiment without any order between a pixel's slices; WRONG frames)
+                        if (false) {}
+#else
+                        if (CHAIN && !PIXELS && ra.n_slices > 1) store_float4_sc1(ra.accum + pix, a);   // another wave continues this pixel: write-through
+#endif
+                        else ra.accum[pix] = a;
                     }
-                    have = false;
+                    have = false; finished = true;
                 }
             }
             RT_STAMP(6);
         }
+        // ---- units whose last pixel-slice ended in this trip: hand the tile's next slice to whoever pops it ------------
+        if (!PIXELS && CHAIN) {
+            const unsigned long long fin = __ballot(finished);
+#ifdef RT_EXP_NOSYNC
+            const int n_slices = 1;
+#else
+            const int n_slices = fin != 0ull ? load_kernarg<int>(offsetof(RenderKernArgs, ra) + offsetof(RenderArgs, n_slices)) : 1;
+#endif
+            if (n_slices > 1) {
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const int cnt = __popcll(fin & __ballot(slot == u));
+                    if (cnt == 0) continue;
+                    left_word -= uint32_t(cnt) << (8u * u);
+                    if (((left_word >> (8u * u)) & 0xffu) != 0u) continue;
+                    const uint32_t id = u == 0u ? uid0 : (u == 1u ? uid1 : (u == 2u ? uid2 : uid3));
+                    const int k_next = int(id >> kUnitTileBits) + 1;
+                    if (k_next < n_slices) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every pixel-slice of the unit (stores of this wave's lanes) is in memory
+                        unsigned int* tile_state = load_kernarg<unsigned int*>(offsetof(RenderKernArgs, ra) + offsetof(RenderArgs, tile_state));
+                        uint32_t old = 0u;
+                        if (lane == 0) old = atomicAdd(tile_state + (id & kUnitTileMask), 1u);
+                        old = uint32_t(__builtin_amdgcn_readfirstlane(int(old)));
+                        if (old & (1u << (8 + k_next))) {                      // the counter has handed the next slice out already: it is this wave's now
+                            const uint32_t nid = id + (1u << kUnitTileBits);
+                            uid0 = u == 0u ? nid : uid0; uid1 = u == 1u ? nid : uid1; uid2 = u == 2u ? nid : uid2; uid3 = u == 3u ? nid : uid3;
+                            mine |= 1u << u;                                   // (the slot stays taken until that unit has been begun)
+                        }
+                    }
+                }
+            }
+        }
     }
 #ifdef RT_STAMPS
+    if (lane == 0) {   // when this wave started and ended (s_memtime), for the frame's timeline (tools/wave_times.py)
+        const unsigned int wid = blockIdx.x * (kBlock / 64) + threadIdx.x / 64;
+        if (wid < 8192u) { g_wave_times[wid][0] = t_wave_start; g_wave_times[wid][1] = __builtin_amdgcn_s_memtime(); }
+    }
     if (ra_entry.stamps) {
         for (int k = 0; k < 8; ++k) if (lane == 0) atomicAdd(ra_entry.stamps + k, stp.t[k]);
         for (int k = 0; k < 4; ++k) atomicAdd(ra_entry.stamps + 8 + k, (unsigned long long)stp.cnt[k]);
@@ -1136,14 +1288,17 @@ __global__ __launch_bounds__(256) void tail_sum_kernel(RenderArgs ra) {
     const int y = ra.y_begin + (ra.band_first + (tile / tiles_x) * ra.band_stride) * kTile + (in >> 3);
     if (!(x < ra.W && y < ra.y_begin + ra.y_count)) return;
     const float4* __restrict__ c = ra.tail + (size_t(tt) * size_t(ra.spp_count) * 64u + size_t(in));
+    const uint32_t pix = uint32_t(y) * uint32_t(ra.W) + uint32_t(x);
     V3 sum = v3(0.0f, 0.0f, 0.0f);
+    float wn = 0.0f;
+    if (ra.flags & RT_RENDER_CONTINUE) { const float4 o = ra.accum[pix]; sum = v3(o.x, o.y, o.z); wn = o.w; }
 #pragma unroll 8
     for (int s = 0; s < ra.spp_count; ++s) {
         const float4 v = c[size_t(s) * 64u];
         sum = sum + v3(v.x, v.y, v.z);
+        wn += 1.0f;
     }
-    const uint32_t pix = uint32_t(y) * uint32_t(ra.W) + uint32_t(x);
-    float4 a = make_float4(sum.x, sum.y, sum.z, float(ra.spp_count));
+    float4 a = make_float4(sum.x, sum.y, sum.z, wn);
     if (ra.flags & RT_RENDER_ACCUMULATE) {
         const float4 o = ra.accum[pix];
         a = make_float4(o.x + sum.x, o.y + sum.y, o.z + sum.z, o.w + float(ra.spp_count));
@@ -1284,8 +1439,9 @@ __global__ void tonemap_kernel(int W, int H, const float4* __restrict__ accum, i
 constexpr int kNoAllocMaxDepth = RT_NOALLOC_MAX_DEPTH;
 constexpr int kNoAllocMaxGrid = 1024;
 constexpr size_t kScratchCounterBytes = 256;
-constexpr size_t kScratchBytes =
-    kScratchCounterBytes + size_t(kNoAllocMaxDepth - kLdsLevels) * size_t(kNoAllocMaxGrid) * kBlock * sizeof(float4);
+constexpr size_t kScratchStackBytes = size_t(kNoAllocMaxDepth - kLdsLevels) * size_t(kNoAllocMaxGrid) * kBlock * sizeof(float4);
+constexpr size_t kScratchDoneTiles = size_t(1) << 20;   // tile_state words of render_kernel: frames of up to 2^20 tiles of 8x8 pixels (67 Mpixel); larger ones: whole pixels
+constexpr size_t kScratchBytes = kScratchCounterBytes + kScratchStackBytes + kScratchDoneTiles * sizeof(unsigned int);
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 namespace {
@@ -1323,8 +1479,13 @@ struct Context {
     size_t stack_bytes = 0;
     void* counters = nullptr;   // [0] unsigned int: tile counter of render_kernel; [8] unsigned long long: verify mismatches
     int render_blocks_per_cu = 0;
-    void* tail = nullptr;               // colours of the frame's tail tiles (render_kernel, tail_sum_kernel; grow-only)
-    size_t tail_bytes = 0;
+    void* queue = nullptr;              // render_kernel's tile_state words (grow-only, 4 bytes per 8x8 tile)
+    size_t queue_bytes = 0;
+    int slice_min = 8, slice_max = kMaxSlices;   // rt_set_sample_slices
+    void* tail = nullptr;               // colours of the frame's tail tiles (render_kernel, tail_sum_kernel); grown on demand up to tail_limit_mb,
+    size_t tail_bytes = 0;              // released by rt_set_tail_limit / rt_upload_scene / rt_shutdown
+    long long tail_limit_mb = 2048;     // rt_set_tail_limit
+    bool slices_always = false;         // RT_SLICES_ALWAYS=1 (tests, tools): sample slices also where the tail has its full size
     void* pix_sort = nullptr;           // rt_render_pixels: tile keys in / out, sorted pixel indices, radix-sort workspace (grow-only)
     size_t pix_sort_bytes = 0;
     hipStream_t own_stream = nullptr;   // created by rt_init; `stream` is this one unless rt_set_stream handed in the caller's
@@ -1541,6 +1702,39 @@ void build_group(const std::vector<float4>& bound, const std::vector<float>& r2k
     fg.margin_k = margin_k;
 }
 
+// The sample slices of one call (render_kernel): begin[0] = 0 < begin[1] < ... < begin[n] = spp, returns n <= smax.
+// The LAST slice has smin samples (a lane's last unit of work is small, so no lane waits long for another's at the end of the
+// frame) and every slice is at most twice its successor, as large as that allows (large units while the frame is in full swing:
+// a lane asks for work rarely, and a tile's units are handed on rarely). If smax slices of that shape cannot hold spp samples
+// the smallest slice grows. Frames with fewer tiles than waves gain nothing from slices beyond the first few (a tile's slices
+// run one after the other whatever their size), but lose nothing either.
+int make_slices(int spp, long long n_tiles, long long waves, int smin, int smax, int* begin) {
+    (void)n_tiles; (void)waves;
+    const double r = 0.5;
+    int sizes[kMaxSlices];   // from the last slice backwards
+    int n = 0;
+    for (double unit = double(smin);; unit *= 1.25) {
+        long long sum = 0;
+        double cur = unit;
+        n = 0;
+        while (n < smax && sum < spp) {
+            sizes[n] = int(cur) < smin ? smin : int(cur);
+            sum += sizes[n++];
+            cur /= r;
+            if (cur > 2.0e9) cur = 2.0e9;
+        }
+        if (sum < spp) continue;
+        int excess = int(sum - spp);                           // the first slice (sizes[n - 1]) takes what is left
+        while (n > 1 && excess >= sizes[n - 1]) excess -= sizes[--n];
+        sizes[n - 1] -= excess;
+        if (n > 1 && (sizes[n - 1] < smin || 2 * sizes[n - 1] <= sizes[n - 2])) { sizes[n - 2] += sizes[n - 1]; --n; }   // a small first slice joins the second
+        break;
+    }
+    begin[0] = 0;
+    for (int k = 0; k < n; ++k) begin[k + 1] = begin[k] + sizes[n - 1 - k];
+    return n;
+}
+
 int grid_for(int n_tiles) {
     int resident = G().prop.multiProcessorCount * 8;   // 8 blocks of 256 threads per CU = 32 waves/CU
     return n_tiles < resident ? (n_tiles > 0 ? n_tiles : 1) : resident;
@@ -1552,21 +1746,16 @@ extern "C" {
 
 const char* rt_last_error(void) { return g_err.c_str(); }
 
-int rt_init(int device) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) return fail("no HIP device available (%s); this library has no CPU fallback", hipGetErrorString(e));
-    if (device < 0 || device >= n || device >= kMaxDevices) return fail("device %d out of range (0..%d)", device, (n < kMaxDevices ? n : kMaxDevices) - 1);
-    g_cur = &g_ctx[device];
-    HIP_OK(hipSetDevice(device));
-    if (G().ready) return 0;
-    HIP_OK(hipGetDeviceProperties(&G().prop, device));
-    HIP_OK(hipStreamCreateWithFlags(&G().own_stream, hipStreamNonBlocking));
-    G().stream = G().own_stream;
-    HIP_OK(hipEventCreate(&G().ev0));
-    HIP_OK(hipEventCreate(&G().ev1));
-    HIP_OK(hipMalloc(&G().counters, 128));
-    HIP_OK(hipMemset(G().counters, 0, 128));
+// Everything rt_init creates, on a context that is not yet visible to anyone: a failure part-way leaves nothing behind
+// (rt_init releases what was created) and a retry starts from scratch.
+static int init_context(Context& c, int device) {
+    HIP_OK(hipGetDeviceProperties(&c.prop, device));
+    HIP_OK(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
+    c.stream = c.own_stream;
+    HIP_OK(hipEventCreate(&c.ev0));
+    HIP_OK(hipEventCreate(&c.ev1));
+    HIP_OK(hipMalloc(&c.counters, 128));
+    HIP_OK(hipMemset(c.counters, 0, 128));
     if (!g_scratch_ptr[device]) {   // once per device, with that device current
         void* sp = nullptr;
         HIP_OK(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
@@ -1575,9 +1764,47 @@ int rt_init(int device) {
     }
     int per_cu = 0;
     HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, false, 0>, kBlock, 0));
-    G().render_blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
-    G().device = device;
-    G().ready = true;
+    c.render_blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    if (const char* e = getenv("RT_SLICES_ALWAYS")) c.slices_always = atoi(e) != 0;
+    if (const char* e = getenv("RT_TAIL_MB")) { const long long v = atoll(e); if (v >= 0) c.tail_limit_mb = v; }
+    if (const char* e = getenv("RT_SLICE_MIN")) { const int v = atoi(e); if (v >= 0) c.slice_min = v; }   // tools/: 0 = whole pixels
+    c.device = device;
+    return 0;
+}
+// releases what a context holds (the device must be current); the context can be initialised again afterwards
+static void destroy_context(Context& c) {
+    if (c.stream) (void)hipStreamSynchronize(c.stream);
+    for (void* p : c.scene_bufs) (void)hipFree(p);
+    c.scene_bufs.clear();
+    if (c.stack) (void)hipFree(c.stack);
+    if (c.counters) (void)hipFree(c.counters);
+    if (c.pix_sort) (void)hipFree(c.pix_sort);
+    if (c.queue) (void)hipFree(c.queue);
+    if (c.tail) (void)hipFree(c.tail);
+    if (c.ev0) (void)hipEventDestroy(c.ev0);
+    if (c.ev1) (void)hipEventDestroy(c.ev1);
+    if (c.own_stream) (void)hipStreamDestroy(c.own_stream);
+    c = Context{};
+}
+
+int rt_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail("no HIP device available (%s); this library has no CPU fallback", hipGetErrorString(e));
+    if (device < 0 || device >= n || device >= kMaxDevices) return fail("device %d out of range (0..%d)", device, (n < kMaxDevices ? n : kMaxDevices) - 1);
+    HIP_OK(hipSetDevice(device));
+    if (!g_ctx[device].ready) {
+        Context fresh;
+        if (init_context(fresh, device)) {   // (the error message is set) nothing of the attempt stays behind
+            const std::string msg = g_err;
+            destroy_context(fresh);
+            g_err = msg;
+            return 1;
+        }
+        fresh.ready = true;
+        g_ctx[device] = fresh;
+    }
+    g_cur = &g_ctx[device];   // only a context that is ready becomes a thread's current one
     return 0;
 }
 
@@ -1613,23 +1840,31 @@ int rt_reset_stream(void) {
     return 0;
 }
 
+int rt_set_sample_slices(int min_samples, int max_slices) {
+    if (need_ready()) return 1;
+    if (min_samples < 0 || max_slices < 1) return fail("rt_set_sample_slices: bad arguments %d, %d", min_samples, max_slices);
+    G().slice_min = min_samples;
+    G().slice_max = max_slices < kMaxSlices ? max_slices : kMaxSlices;
+    return 0;
+}
+
+int rt_set_tail_limit(int64_t megabytes) {
+    if (need_ready()) return 1;
+    if (megabytes < 0 || megabytes > (int64_t(1) << 20)) return fail("rt_set_tail_limit: %lld MiB outside 0..2^20", (long long)megabytes);
+    if (settle()) return 1;
+    HIP_OK(hipStreamSynchronize(G().stream));
+    G().tail_limit_mb = megabytes;
+    if (G().tail && G().tail_bytes > size_t(megabytes) << 20) {   // what is held beyond the new limit goes back at once
+        HIP_OK(hipFree(G().tail));
+        G().tail = nullptr; G().tail_bytes = 0;
+    }
+    return 0;
+}
+
 void rt_shutdown(void) {
     if (!G().ready) return;
     (void)hipSetDevice(G().device);
-    (void)hipStreamSynchronize(G().stream);
-    free_scene();
-    if (G().stack) (void)hipFree(G().stack);
-    G().stack = nullptr; G().stack_bytes = 0;
-    if (G().counters) (void)hipFree(G().counters);
-    G().counters = nullptr;
-    if (G().pix_sort) (void)hipFree(G().pix_sort);
-    G().pix_sort = nullptr; G().pix_sort_bytes = 0;
-    if (G().tail) (void)hipFree(G().tail);
-    G().tail = nullptr; G().tail_bytes = 0;
-    (void)hipEventDestroy(G().ev0); (void)hipEventDestroy(G().ev1);
-    (void)hipStreamDestroy(G().own_stream);
-    G().own_stream = nullptr; G().stream = nullptr;
-    G().ready = false; G().have_cam = false; G().have_scene = false; G().pending = false; G().device = -1;
+    destroy_context(G());
 }
 
 int rt_device_info(char* buf, int buflen) {
@@ -2019,6 +2254,7 @@ int rt_upload_scene(const RtScene* s) {
     if (settle()) return 1;
     HIP_OK(hipStreamSynchronize(G().stream));
     free_scene();
+    if (G().tail) { (void)hipFree(G().tail); G().tail = nullptr; G().tail_bytes = 0; }   // a new scene: the colour buffer comes back with the next frame that wants it
     DevScene ds{};
     ds.n_rect_xy = n_rect_axis[0]; ds.n_rect_xz = n_rect_axis[1]; ds.rect_extent = rect_extent;
     ds.n_sph = int(sph.size()); ds.n_rect = int(rect_axis.size()); ds.n_tri = int(tri_prim.size()); ds.n_prims = s->n_prims;
@@ -2167,7 +2403,8 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
         int n = w * tiles_y * kTile;
         if (begin_timed()) return 1;
         hipLaunchKernelGGL(render_black_kernel, dim3((n + 255) / 256), dim3(256), 0, G().stream, w, y_begin, y_count, band_first, band_stride, tiles_y,
-                           spp_count, flags, reinterpret_cast<float4*>(d_accum));
+                           spp_count, (flags & RT_RENDER_CONTINUE) ? (flags | RT_RENDER_ACCUMULATE) : flags,   // (continuing with black samples adds +0)
+                           reinterpret_cast<float4*>(d_accum));
         return finish_timed(1, (flags & RT_RENDER_NOWAIT) != 0);
     }
     const int n_tiles = ((w + kTile - 1) / kTile) * tiles_y;   // one 8x8 tile per wave at a time
@@ -2176,26 +2413,34 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     if (const char* e = getenv("RT_BPC")) resident = G().prop.multiProcessorCount * atoi(e);   // diagnostic: blocks per CU
 #endif
     if (settle()) return 1;   // a launch still in flight owns the counters and the stack
-    // The tail (render_kernel): n_tail tiles spread over the frame are handed out last, as units of `chunk` samples per pixel.
-    // To keep every lane fed until the last whole pixel is done they must hold about as much work as the frame's most
-    // expensive pixel takes on every lane - several tiles per wave; measured (tools/tail_sweep.py, 1080p at 64 samples, 8 tiles
-    // per wave): half the frame is best (the 9.8k-triangle frame 68 -> 53 ms), all of it 5 % worse again (a lane then asks for work
-    // every few samples). So: half the frame, at most 4 tiles per resident wave, all of a frame of at most 2 tiles per wave, and
-    // no more than a colour buffer of 4 GiB holds (16 bytes per sample: 16384 tiles at 256 samples; the 4K frame of 256 samples
-    // takes 420 ms without a tail, 416 / 412 / 408 ms with 1 / 2 / 4 GiB). RT_TAIL_MAX_MB changes the limit, 0 = no tail.
+    // Sample slices (render_kernel): make_slices. RT_RENDER_ACCUMULATE adds the pass's own sum to what was there, which a chain of
+    // slices through the accumulator cannot express: one slice. rt_set_sample_slices changes the smallest slice (0: whole pixels)
+    // and the slice limit.
+    if ((flags & RT_RENDER_ACCUMULATE) && (flags & RT_RENDER_CONTINUE)) return fail("%s: RT_RENDER_ACCUMULATE and RT_RENDER_CONTINUE exclude each other", who);
+    if ((long long)n_tiles * 64 > kMaxWorkItems)
+        return fail("%s: %d tiles of 8x8 pixels exceed what one call hands out (33.5 million); split the rows over several calls", who, n_tiles);
+    RenderArgs ra{};
+    const long long waves = (long long)resident * (kBlock / 64);
+    // Two ways to keep every lane fed until a frame ends, both leaving the bits of a pixel summed by one thread:
+    // * the tail (render_kernel): n_tail tiles spread evenly over the frame are kept for its end and rendered in units of 8 samples
+    //   per pixel whose colours go through a buffer (16 bytes per sample), parallel over a pixel's samples as well. Measured best
+    //   (tools/tail_sweep.py, round 2): half the frame's tiles, at most four per resident wave, all tiles of a frame with at most
+    //   two tiles per wave. That costs 1 KiB per tile and sample: 1 GiB for a 1080p frame of 64 samples, 4 GiB for 16384 tiles of
+    //   a 4K frame of 256, 16 GiB at 1024 samples - so it is bounded (rt_set_tail_limit, default 2 GiB);
+    // * sample slices (make_slices): where that limit leaves less than half the tail the frame would like, the other tiles are rendered slice by slice through
+    //   the accumulator instead of as whole pixels: no memory to speak of, units that shrink towards the frame's end, but a
+    //   tile's slices come one after the other, so the slowest tiles' last slices keep a few waves busy after the others have
+    //   left (15 % of a 1080p frame of the triangle mesh without a tail), and the bookkeeping costs 1 - 2 %: second choice.
     int chunk = 8, n_tail = 0, chunks = 1;
-    if (const char* e = getenv("RT_TAIL_CHUNK")) { const int c = atoi(e); if (c >= 1) chunk = c; }   // (the two switches: tests and tools/tail_sweep.py)
-    if (!scratch_dev && spp_count >= 2 * chunk) {
-        const long long waves = (long long)resident * (kBlock / 64);
+    bool tail_short = true;             // the tail is smaller than the frame would like (or there is none)
+    if (!scratch_dev && G().tail_limit_mb > 0 && spp_count >= 2 * chunk) {
+        tail_short = false;
         long long t = n_tiles <= 2 * waves ? n_tiles : (n_tiles / 2 < 4 * waves ? n_tiles / 2 : 4 * waves);
-        if (const char* e = getenv("RT_TAIL_TILES")) { t = atoll(e); if (t > n_tiles) t = n_tiles; if (t < 0) t = 0; }
         const long long per_tile = (long long)spp_count * 64 * (long long)sizeof(float4);
-        long long cap_mb = 4096;
-        if (const char* e = getenv("RT_TAIL_MAX_MB")) { cap_mb = atoll(e); if (cap_mb < 0) cap_mb = 0; if (cap_mb > 32768) cap_mb = 32768; }
-        const long long cap = (cap_mb << 20) / per_tile;
-        if (t > cap) t = cap;
+        const long long cap = (G().tail_limit_mb << 20) / per_tile;
+        if (t > cap) { tail_short = 2 * cap < t; t = cap; }   // (half the tail it would like still beats slices: 4K / 256 spp 384.8 against 389.9 ms)
         chunks = (spp_count + chunk - 1) / chunk;
-        if (t * chunks * 64 + (long long)(n_tiles - t) * 64 > 0x7fffff00ll) t = 0;   // the work counter is 32 bits wide
+        if (t * chunks * 64 > kMaxWorkItems / 2) t = 0;
         n_tail = int(t);
         if (n_tail > 0 && size_t(n_tail * per_tile) > G().tail_bytes) {
             if (G().tail) HIP_OK(hipFree(G().tail));
@@ -2206,32 +2451,59 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
                 G().tail = nullptr;
                 n_tail /= 2;
             }
+            if (2 * (long long)n_tail < t) tail_short = true;
             G().tail_bytes = size_t(n_tail * per_tile);
         }
     }
     if (n_tail == 0) chunks = 1;
-    const long long units = (long long)(n_tiles - n_tail) + (long long)n_tail * chunks;
+    const int n_bulk = n_tiles - n_tail;
+    {
+        const int smin = G().slice_min;
+        int n = 0;
+        ra.slice_begin[0] = 0;
+        const bool one = !(tail_short || G().slices_always) || n_bulk == 0 || smin <= 0 || spp_count < 2 * smin || (flags & RT_RENDER_ACCUMULATE) || G().slice_max < 2;
+        if (!one) {
+            int smax = G().slice_max < kMaxSlices ? G().slice_max : kMaxSlices;
+            if (scratch_dev && (long long)n_bulk > (long long)kScratchDoneTiles) smax = 1;   // (the scratch array holds the state words of that many tiles)
+            while (smax > 1 && (long long)n_bulk * smax * 64 > kMaxWorkItems / 2) --smax;   // the work counter is 32 bits wide
+            if (n_bulk > int(kUnitTileMask)) smax = 1;                                       // (a unit word holds the tile in 26 bits)
+            if (smax >= 2) n = make_slices(spp_count, n_bulk, waves, smin, smax, ra.slice_begin);
+        }
+        if (n == 0) { n = 1; ra.slice_begin[1] = spp_count; }
+        ra.n_slices = n; ra.n_tiles = n_bulk;
+    }
+    ra.n_tail_tiles = n_tail; ra.tail_chunk = chunk; ra.tail_chunks = chunks;
+    ra.tail_stride = n_tail > 0 ? n_tiles / n_tail : 1;
+    ra.tail = static_cast<float4*>(G().tail);
+    const size_t queue_bytes = (size_t(n_bulk > 0 ? n_bulk : 1) * sizeof(unsigned int) + 255) / 256 * 256;   // tile_state: one word per tile
+    const long long units = (long long)n_bulk * ra.n_slices + (long long)n_tail * chunks;
     const long long want = (units + 3) / 4;
     int grid = want < resident ? int(want) : resident;
     void* counters = G().counters;
     float4* stack = nullptr;
+    unsigned int* queue = nullptr;
     if (scratch_dev) {   // the stack part of `scratch` holds kNoAllocMaxDepth - kLdsLevels levels of kNoAllocMaxGrid blocks
         if (grid > kNoAllocMaxGrid) grid = kNoAllocMaxGrid;
         counters = scratch_dev;
         stack = reinterpret_cast<float4*>(static_cast<char*>(scratch_dev) + kScratchCounterBytes);
+        queue = reinterpret_cast<unsigned int*>(static_cast<char*>(scratch_dev) + kScratchCounterBytes + kScratchStackBytes);
     } else {
         if (ensure_stack(depth, grid)) return 1;
         stack = static_cast<float4*>(G().stack);
+        if (ra.n_slices > 1 && queue_bytes > G().queue_bytes) {
+            if (G().queue) HIP_OK(hipFree(G().queue));
+            G().queue = nullptr; G().queue_bytes = 0;
+            HIP_OK(hipMalloc(&G().queue, queue_bytes));
+            G().queue_bytes = queue_bytes;
+        }
+        queue = static_cast<unsigned int*>(G().queue);
     }
-    RenderArgs ra{};
     ra.W = w; ra.H = h; ra.y_begin = y_begin; ra.y_count = y_count; ra.spp_begin = spp_begin; ra.spp_count = spp_count; ra.depth = depth;
     ra.band_first = band_first; ra.band_stride = band_stride; ra.tiles_y = tiles_y;
     ra.seed = seed; ra.flags = flags;
     ra.inv_w = 1.0 / double(float(w)); ra.inv_h = 1.0 / double(float(h));
     ra.accum = reinterpret_cast<float4*>(d_accum); ra.stack = stack;
-    ra.n_bulk_tiles = n_tiles - n_tail; ra.n_tail_tiles = n_tail; ra.tail_chunk = chunk; ra.tail_chunks = chunks;
-    ra.tail_stride = n_tail > 0 ? n_tiles / n_tail : 1;
-    ra.tail = static_cast<float4*>(G().tail);
+    ra.tile_state = ra.n_slices > 1 ? queue : nullptr;
     ra.rays_out = reinterpret_cast<unsigned long long*>(d_rays);
     ra.work_counter = static_cast<unsigned int*>(counters);
     ra.mismatches = reinterpret_cast<unsigned long long*>(static_cast<char*>(counters) + 8);
@@ -2243,18 +2515,24 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     HIP_OK(hipMemsetAsync(counters, 0, 128, G().stream));
 #else
     ra.stamps = nullptr;
-    HIP_OK(hipMemsetAsync(counters, 0, verify ? 16 : 4, G().stream));
+    HIP_OK(hipMemsetAsync(counters, 0, 16, G().stream));
 #endif
+    if (ra.n_slices > 1) {   // no slice of any tile is finished, none has been left to another wave
+        HIP_OK(hipMemsetAsync(queue, 0, queue_bytes, G().stream));
+    }
     if (begin_timed()) return 1;
     const bool many_rects = G().scene.n_rect >= kRectFlagMin;
     const bool bvh = G().scene.tbvh != nullptr && !many_rects;   // (a scene with many rects AND a triangle BVH takes the flat triangle path)
-    if (G().scene.n_med > 0) hipLaunchKernelGGL((render_kernel<false, false, 0, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
-    else if (verify && bvh) hipLaunchKernelGGL((render_kernel<true, false, 0, 0, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
-    else if (bvh) hipLaunchKernelGGL((render_kernel<false, false, 0, 0, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
-    else if (verify && many_rects) hipLaunchKernelGGL((render_kernel<true, false, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
-    else if (verify) hipLaunchKernelGGL((render_kernel<true, false, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
-    else if (many_rects) hipLaunchKernelGGL((render_kernel<false, false, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
-    else hipLaunchKernelGGL((render_kernel<false, false, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    const bool chain = ra.n_slices > 1;
+#define RT_LAUNCH(...) hipLaunchKernelGGL((render_kernel<__VA_ARGS__>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra)
+    if (G().scene.n_med > 0) { if (chain) RT_LAUNCH(false, false, 0, 1, 0, true); else RT_LAUNCH(false, false, 0, 1, 0, false); }
+    else if (verify && bvh) RT_LAUNCH(true, false, 0, 0, 1, true);
+    else if (bvh) { if (chain) RT_LAUNCH(false, false, 0, 0, 1, true); else RT_LAUNCH(false, false, 0, 0, 1, false); }
+    else if (verify && many_rects) RT_LAUNCH(true, false, 1, 0, 0, true);
+    else if (verify) RT_LAUNCH(true, false, 0, 0, 0, true);
+    else if (many_rects) { if (chain) RT_LAUNCH(false, false, 1, 0, 0, true); else RT_LAUNCH(false, false, 1, 0, 0, false); }
+    else { if (chain) RT_LAUNCH(false, false, 0, 0, 0, true); else RT_LAUNCH(false, false, 0, 0, 0, false); }
+#undef RT_LAUNCH
     if (n_tail > 0) hipLaunchKernelGGL(tail_sum_kernel, dim3((n_tail * 64 + 255) / 256), dim3(256), 0, G().stream, ra);
     return finish_timed(n_tail > 0 ? 2 : 1, (flags & RT_RENDER_NOWAIT) != 0);
 }
@@ -2301,11 +2579,11 @@ int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_b
                      float* d_accum, uint64_t* d_rays) {
     if (need_scene_cam()) return 1;
     if (w <= 0 || h <= 0 || (long long)w * h > 0x7fffffffLL) return fail("rt_render_pixels: bad size %dx%d", w, h);
-    if (n < 0 || n > 0x7fffffc0LL) return fail("rt_render_pixels: bad pixel count %lld", (long long)n);
+    if (n < 0 || n > kMaxWorkItems) return fail("rt_render_pixels: bad pixel count %lld", (long long)n);
     if (spp_begin < 0 || spp_count < 0) return fail("rt_render_pixels: bad sample range [%d,+%d)", spp_begin, spp_count);
     if (depth < 0 || depth > 128) return fail("rt_render_pixels: depth %d outside 0..128", depth);
     if (!d_accum || (n > 0 && !d_pixels)) return fail("rt_render_pixels: null pointer");
-    if (flags & RT_RENDER_VERIFY) return fail("rt_render_pixels: RT_RENDER_VERIFY is an rt_render flag");
+    if (flags & (RT_RENDER_VERIFY | RT_RENDER_CONTINUE)) return fail("rt_render_pixels: RT_RENDER_VERIFY and RT_RENDER_CONTINUE are rt_render flags");
     if (n == 0) { G().last_ms = 0; G().last_launches = 0; return 0; }
     if (spp_count == 0 || depth == 0) {   // no ray is traced: every sample is black (calc.cpp:96-97)
         if (begin_timed()) return 1;
@@ -2328,6 +2606,8 @@ int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_b
     ra.work_counter = static_cast<unsigned int*>(G().counters);
     ra.mismatches = nullptr; ra.stamps = nullptr;
     ra.pixels = d_pixels; ra.n_pixels = int(n);
+    ra.n_slices = 1; ra.n_tiles = 0; ra.slice_begin[1] = spp_count; ra.tile_state = nullptr;
+    ra.n_tail_tiles = 0; ra.tail_chunk = 8; ra.tail_chunks = 1; ra.tail_stride = 1; ra.tail = nullptr;
     HIP_OK(hipMemsetAsync(G().counters, 0, 4, G().stream));
     // The list is rendered 64 entries per wave in list order. The reference draws its pixels at random (rayview.cpp:69-70), and a
     // wave whose 64 primary rays go 64 different ways filters the union of what they need: 43 % slower than the same pixels in
@@ -2360,14 +2640,21 @@ int rt_render_pixels(int w, int h, int64_t n, const int32_t* d_pixels, int spp_b
         ra.pixels = sorted;
         launches = 3;
     } else if (begin_timed()) return 1;
-    if (G().scene.n_med > 0) hipLaunchKernelGGL((render_kernel<false, true, 0, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
-    else if (G().scene.tbvh != nullptr && G().scene.n_rect < kRectFlagMin) hipLaunchKernelGGL((render_kernel<false, true, 0, 0, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
-    else if (G().scene.n_rect >= kRectFlagMin) hipLaunchKernelGGL((render_kernel<false, true, 1>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
-    else hipLaunchKernelGGL((render_kernel<false, true, 0>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    if (G().scene.n_med > 0) hipLaunchKernelGGL((render_kernel<false, true, 0, 1, 0, false>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    else if (G().scene.tbvh != nullptr && G().scene.n_rect < kRectFlagMin) hipLaunchKernelGGL((render_kernel<false, true, 0, 0, 1, false>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    else if (G().scene.n_rect >= kRectFlagMin) hipLaunchKernelGGL((render_kernel<false, true, 1, 0, 0, false>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
+    else hipLaunchKernelGGL((render_kernel<false, true, 0, 0, 0, false>), dim3(grid), dim3(kBlock), 0, G().stream, G().scene, G().cam, ra);
     return finish_timed(launches);
 }
 
 #ifdef RT_STAMPS
+// diagnostic builds only (tools/wave_times.py): start and end time of every wave of the last render
+int rt_debug_wave_times(uint64_t* out, int n_waves) {
+    if (need_ready()) return 1;
+    HIP_OK(hipStreamSynchronize(G().stream));
+    HIP_OK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_times), size_t(n_waves) * 16, 0, hipMemcpyDeviceToHost));
+    return 0;
+}
 // diagnostic builds only (tools/): section cycles and pass counts of the last render
 int rt_debug_stamps(uint64_t out[12]) {
     if (need_ready()) return 1;

@@ -99,10 +99,12 @@ struct Stamps {
 #define RT_COUNT(i) do { if ((__ffsll((long long)__ballot(1)) - 1) == int(threadIdx.x & 63)) ++stp.cnt[i]; } while (0)
 #define RT_COUNT_LANES(i) do { ++stp.cnt[i]; } while (0)
 #define RT_STAMP_PARAM , Stamps& stp
+#define RT_EVENT(i) do { stp.t[i] += 1; } while (0)   /* wave-uniform event counts in the unused time slots */
 #define RT_BATCHES(act) do { stp.t[1] += __builtin_popcount(act); } while (0)
 #define RT_STAMP_ARG , stp
 #else
 #define RT_COUNT_LANES(i) do {} while (0)
+#define RT_EVENT(i) do {} while (0)
 #define RT_BATCHES(act) do {} while (0)
 #define RT_STAMP(i) do {} while (0)
 #define RT_COUNT(i) do {} while (0)

@@ -211,7 +211,7 @@ inline std::vector<uint32_t> renderAll(int width, int height, int samples, const
 
 // RayView::go (rayview.cpp:98-117) for the GPU. The reference spends each 16 ms slice on random
 // pixels, every one rendered with all its samples and overwritten on the next visit; here a slice is
-// one or more FULL-FRAME passes of a few samples each, accumulated (RT_RENDER_ACCUMULATE), so the
+// one or more FULL-FRAME passes of a few samples each, continued in sample order (RT_RENDER_CONTINUE), so the
 // picture refines everywhere at once. Sample indices continue across slices (pass k renders samples
 // [done, done + n) of every pixel), so N slices of the same scene give exactly the samples of one
 // N-slice-long render. A scene or camera change (the sphere-Y slider, WASD: rayview.cpp:130-184) is
@@ -249,7 +249,7 @@ public:
         s_.bind();
         double used = 0.0;
         do {
-            rt_host::check(rt_render(w_, h_, 0, h_, done_, per_pass_, depth_, seed_, done_ == 0 ? 0u : RT_RENDER_ACCUMULATE,
+            rt_host::check(rt_render(w_, h_, 0, h_, done_, per_pass_, depth_, seed_, done_ == 0 ? 0u : RT_RENDER_CONTINUE,
                                      (float*)acc_.p, nullptr));
             float ms = 0.0f; int launches = 0;
             rt_last_kernel_ms(&ms, &launches);

@@ -323,9 +323,10 @@ def test_cpp_dropin_host_renderAll(rt, tmp_path):
 
 
 def test_progressive_slices_continue_the_sample_sequence(rt):
-    """RayView::go on the GPU (SURVEY.md 8f row 1): time slices accumulate full-frame passes; after any
-    number of slices the accumulators hold exactly samples [0, n) of every pixel, and reset() (scene
-    mutation, as the sphere-Y slider does) starts over."""
+    """RayView::go on the GPU (SURVEY.md 8f row 1): time slices continue full-frame passes in sample order
+    (RT_RENDER_CONTINUE); after any number of slices the accumulators hold the in-order sum of samples [0, n) of every
+    pixel -- the bits of ONE render of n samples, whatever the passes were -- and reset() (scene mutation, as the
+    sphere-Y slider does) starts over."""
     from ray_amd import api
     sc = scenes.builtin_scene()
     rt.upload_scene(sc)
@@ -337,8 +338,7 @@ def test_progressive_slices_continue_the_sample_sequence(rt):
     acc = pv.accumulators()
     assert (acc[..., 3] == n2).all()
     oacc, _ = O.render(sc, W, H, n2, depth, rng_mode=1, seed64=21, math_mode=1, n_threads=8)
-    # passes add partial sums: two orders of adding n2 samples differ by a few sqrt(n2) ulp (n2 depends on the kernel's speed)
-    np.testing.assert_allclose(acc[..., :3], oacc[..., :3], rtol=max(3e-6, 4e-7 * np.sqrt(n2)), atol=1e-6)
+    assert O.same_bits_or_nan(acc, oacc)          # passes continue the sum in sample order: no tolerance
     img = pv.image()
     assert img.shape == (H, W) and (img >> 24 == 0xff).all()
     moved = scenes.builtin_scene(sphere_y=0.8)
@@ -347,7 +347,7 @@ def test_progressive_slices_continue_the_sample_sequence(rt):
     acc3 = pv.accumulators()
     o3, _ = O.render(moved, W, H, n3, depth, rng_mode=1, seed64=21, math_mode=1, n_threads=8)
     assert (acc3[..., 3] == n3).all()
-    np.testing.assert_allclose(acc3[..., :3], o3[..., :3], rtol=3e-6, atol=1e-6)
+    assert O.same_bits_or_nan(acc3, o3)
 
 
 @pytest.mark.parametrize("name,kw,W,H,rows", [
@@ -995,50 +995,91 @@ def test_render_pixels_long_lists_are_sorted_by_tile_first(rt, W, H):
         acc.free(); dpx.free(); rays.free()
 
 
-def test_tail_units_give_the_same_frame(rt, monkeypatch):
-    """The frame's last tiles are handed out as units of a few samples per pixel whose colours are summed in sample order by a
-    second kernel (render_kernel's tail): whatever share of the frame goes that way and whatever the unit, the
-    accumulators, the ray count and the oracle's frame are the same bits. Ragged frame (partial tiles), a sample count
-    that is no multiple of the unit, ACCUMULATE on top of an earlier pass, interleaved bands."""
+def test_sample_slices_give_the_same_frame(rt):
+    """render_kernel hands a pixel's samples out as consecutive slices: a lane that takes a pixel of a later
+    slice continues the sum the earlier slices left in the accumulator, in sample order, and waits for them through a per-tile
+    counter. Whatever the slices, the accumulators, the ray count and the oracle's frame are the same bits. Ragged frame (partial
+    tiles), sample counts that are no multiple of the unit, units of 1 sample on a frame with far fewer tiles than waves (every
+    wave of a later slice waits for the earlier one), RT_RENDER_CONTINUE across calls, ACCUMULATE (one slice), bands."""
     from ray_amd import api
     sc = scenes.get_scene("random", half=3)
     rt.upload_scene(sc)
     W, H, spp, depth = 100, 45, 20, 8
     oacc, orays = O.render(sc, W, H, spp, depth, rng_mode=1, seed64=77, math_mode=1, n_threads=8)
-    n_tiles = ((W + 7) // 8) * ((H + 7) // 8)
-    for tiles, chunk, launches in [("0", None, 1), (None, None, 2), ("5", None, 2), (str(n_tiles - 1), "3", 2), ("7", "1", 2), ("30", "10", 2),
-                                   ("1000000", "7", 2)]:
-        for k, v in (("RT_TAIL_TILES", tiles), ("RT_TAIL_CHUNK", chunk)):
-            if v is None:
-                monkeypatch.delenv(k, raising=False)
-            else:
-                monkeypatch.setenv(k, v)
+    try:
+        # a frame with fewer tiles than waves goes through the colour buffer of the frame's end entirely (rt_set_tail_limit) ...
         acc, rays = rt.render(W, H, spp, depth, seed=77)
-        assert rt.last_kernel_ms()[1] == launches, (tiles, chunk)
-        assert rays == orays and O.same_bits_or_nan(acc, oacc), (tiles, chunk)
-    monkeypatch.setenv("RT_TAIL_TILES", "40")
-    monkeypatch.setenv("RT_TAIL_CHUNK", "4")
-    # a second pass added to the first: the tail pixels add (old + sum) like the others
-    buf = rt.alloc(W * H * 16).zero()
-    rt.render_into(W, H, buf, spp, depth, seed=77)
-    rt.render_into(W, H, buf, spp, depth, seed=77, flags=api.RENDER_ACCUMULATE)
-    two = buf.to_numpy(np.float32, (H, W, 4))
-    want = oacc + oacc
-    assert O.same_bits_or_nan(two, want)
-    buf.free()
-    # interleaved bands, each with its own tail
-    total = np.zeros_like(oacc)
-    n = 0
-    for r in range(3):
-        part, nr = rt.render(W, H, spp, depth, seed=77, band_first=r, band_stride=3)
-        total += part
-        n += nr
-    assert n == orays and O.same_bits_or_nan(total, oacc)
-    # fewer samples than two units: no tail
-    monkeypatch.delenv("RT_TAIL_TILES")
-    monkeypatch.delenv("RT_TAIL_CHUNK")
-    rt.render(W, H, 15, depth, seed=77)
-    assert rt.last_kernel_ms()[1] == 1
+        assert rt.last_kernel_ms()[1] == 2 and rays == orays and O.same_bits_or_nan(acc, oacc)
+        # ... unless the limit leaves room for some of its 78 tiles only (1 MiB: 51 tiles of 20 KiB), or for none: then slices
+        for mb in (1, 0):
+            rt.set_tail_limit(mb)
+            for smin, smax in [(0, 16), (8, 16), (1, 16), (1, 3), (3, 16), (7, 2), (10, 16), (16, 16), (2, 1)]:
+                rt.set_sample_slices(smin, smax)
+                acc, rays = rt.render(W, H, spp, depth, seed=77)
+                assert rt.last_kernel_ms()[1] == (2 if mb else 1)
+                assert rays == orays and O.same_bits_or_nan(acc, oacc), (mb, smin, smax)
+        rt.set_sample_slices(2, 16)
+        # consecutive sample ranges continued in one accumulator: the bits of the one call, whatever was there before the first
+        buf = rt.alloc(W * H * 16).from_numpy(np.full((H, W, 4), 7.5, np.float32))
+        n = 0
+        r = rt.alloc(8).zero()
+        for s0, cnt in ((0, 7), (7, 5), (12, 0), (12, 8)):
+            rt.render_into(W, H, buf, cnt, depth, seed=77, spp_begin=s0, flags=api.RENDER_CONTINUE if s0 else 0, rays=r)
+        assert int(r.to_numpy(np.uint64, (1,))[0]) == orays
+        assert O.same_bits_or_nan(buf.to_numpy(np.float32, (H, W, 4)), oacc)
+        # a second pass ADDED to the first: old + (the pass's own sum)
+        rt.render_into(W, H, buf, spp, depth, seed=77, flags=api.RENDER_ACCUMULATE)
+        assert O.same_bits_or_nan(buf.to_numpy(np.float32, (H, W, 4)), oacc + oacc)
+        assert rt.lib.rt_render(W, H, 0, H, 0, 4, depth, 77, api.RENDER_ACCUMULATE | api.RENDER_CONTINUE, buf.ptr, None) != 0
+        buf.free(); r.free()
+        # interleaved bands and a row range that starts inside a tile row, each with its own slices
+        total = np.zeros_like(oacc)
+        n = 0
+        for k in range(3):
+            part, nr = rt.render(W, H, spp, depth, seed=77, band_first=k, band_stride=3)
+            total += part
+            n += nr
+        assert n == orays and O.same_bits_or_nan(total, oacc)
+        part, _ = rt.render(W, H, spp, depth, seed=77, y_begin=5, y_count=23)
+        assert O.same_bits_or_nan(part[5:28], oacc[5:28]) and (part[:5] == 0).all() and (part[28:] == 0).all()
+        # the same with some tiles in the colour buffer: continued calls, bands
+        rt.set_tail_limit(1)
+        buf = rt.alloc(W * H * 16).zero()
+        for s0, cnt in ((0, 16), (16, 4)):       # (the second call has too few samples for a tail)
+            rt.render_into(W, H, buf, cnt, depth, seed=77, spp_begin=s0, flags=api.RENDER_CONTINUE if s0 else 0)
+        assert O.same_bits_or_nan(buf.to_numpy(np.float32, (H, W, 4)), oacc)
+        buf.zero()
+        for s0, cnt in ((0, 2), (2, 18)):        # (the second call continues the first THROUGH the tail's sum kernel)
+            rt.render_into(W, H, buf, cnt, depth, seed=77, spp_begin=s0, flags=api.RENDER_CONTINUE if s0 else 0)
+            assert rt.last_kernel_ms()[1] == (2 if s0 else 1)
+        assert O.same_bits_or_nan(buf.to_numpy(np.float32, (H, W, 4)), oacc)
+        rt.render_into(W, H, buf, spp, depth, seed=77, flags=api.RENDER_ACCUMULATE)
+        assert O.same_bits_or_nan(buf.to_numpy(np.float32, (H, W, 4)), oacc + oacc)
+        buf.free()
+        total = np.zeros_like(oacc)
+        for k in range(3):
+            part, nr = rt.render(W, H, spp, depth, seed=77, band_first=k, band_stride=3)
+            total += part
+        assert O.same_bits_or_nan(total, oacc)
+    finally:
+        rt.set_sample_slices(8, 16)
+        rt.set_tail_limit(2048)
+    # a frame with several tiles per wave: the three ways to render it
+    sc2 = scenes.builtin_scene()
+    rt.upload_scene(sc2)
+    a, ra = rt.render(1280, 720, 32, 10, seed=5)          # (whole pixels + half the frame through the colour buffer)
+    rt.set_tail_limit(16)
+    try:
+        c, rc = rt.render(1280, 720, 32, 10, seed=5)      # (the limit cuts the tail short: sample slices + 512 tail tiles)
+        assert rt.last_kernel_ms()[1] == 2 and rc == ra and O.same_bits_or_nan(a, c)
+        rt.set_sample_slices(0, 16)
+        rt.set_tail_limit(0)
+        b, rb = rt.render(1280, 720, 32, 10, seed=5)      # (whole pixels only)
+        assert rt.last_kernel_ms()[1] == 1
+    finally:
+        rt.set_sample_slices(8, 16)
+        rt.set_tail_limit(2048)
+    assert ra == rb and O.same_bits_or_nan(a, b)
 
 
 def test_triangle_queue_overflow_negative_t_and_zero_t(rt):
