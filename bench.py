@@ -155,6 +155,7 @@ def quick_run(ctx, api, scenes, torch, dev, name, frames=1):
             "Mrays_per_s": round(n / dt / 1e6, 1), "rays_per_frame": n // frames}
 
 
+DEFAULT_TAIL_MB, TILE_SPLIT_TAIL_MB = 2048, 20480   # rt_set_tail_limit: the library's default; what a rank of a tile-split job (owning its GPU) allows
 XGMI_LINK_GBPS = 153.0   # one xGMI link of an MI355X (7 per GPU); a ring collective is bound by one link
 
 
@@ -172,6 +173,9 @@ def shares_run(ctx, scenes, torch, dev, frames=3):
         ctx.upload_scene(scenes.get_scene(wl["scene"], **wl["kw"]))
         acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
         bytes_acc = W * H * 16
+        # a rank of a tile-split job owns its GPU: the colour buffer of the frame's end may hold the whole share (1 KiB per tile and
+        # sample: 16.2 GB for the 1/8 share at 1024 spp), which makes the share parallel over samples too (rt_set_tail_limit)
+        ctx.set_tail_limit(TILE_SPLIT_TAIL_MB if kind == "tile" else DEFAULT_TAIL_MB)
 
         def timed(G, n):
             kw = dict(spp_begin=0) if kind == "spp" else dict(band_first=0, band_stride=G)
@@ -194,7 +198,8 @@ def shares_run(ctx, scenes, torch, dev, frames=3):
             ex = ((2.0 if kind == "spp" else 1.0) * (G - 1) / G * bytes_acc / (XGMI_LINK_GBPS * 1e9)) * 1e3
             rows[str(G)] = {"t_share_ms": round(t, 3), "kernel_ms": round(k, 3), "G_t_share_over_t_full": round(G * t / t_full, 4),
                             "t_exchange_est_ms": round(ex, 3), "efficiency_ceiling": round(t_full / (G * (t + ex)), 4)}
-        out[name] = {"workload": wl["desc"], "split": kind, "t_full_ms": round(t_full, 3), "kernel_full_ms": round(k_full, 3), "ranks": rows}
+        ctx.set_tail_limit(DEFAULT_TAIL_MB)
+        out[name] = {"workload": wl["desc"], "split": kind, "tail_limit_mb": TILE_SPLIT_TAIL_MB if kind == "tile" else DEFAULT_TAIL_MB, "t_full_ms": round(t_full, 3), "kernel_full_ms": round(k_full, 3), "ranks": rows}
         del acc
     out["note"] = ("one GPU: the render call of rank 0 of a G-rank job (c3: samples [0, spp/G) of every pixel; c5: bands 0, G, 2G, ... at "
                    "full spp), wall clock per call incl. launch and sync; exchange ESTIMATED as a ring over one 153 GB/s xGMI link on the "
@@ -257,6 +262,8 @@ def main():
     # any fill of the accumulator, and the collective of this step is ordered after the kernel
     ctx.set_stream(torch.cuda.current_stream(dev))
     split = wl["split"] if world > 1 else "none"
+    if split == "tile":
+        ctx.set_tail_limit(TILE_SPLIT_TAIL_MB)
     # work split (ray_amd/dist.py): spp-split = every rank renders all pixels and a slice of the samples, then ONE
     # all-reduce of the accumulators; tile-split = every rank renders all samples of its interleaved 8-row bands,
     # then ONE all-gather of the disjoint bands (no zero fill, no sum)
