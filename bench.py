@@ -93,13 +93,17 @@ def cpu_baseline(scene, wl, budget_s=12.0):
                                    capture_output=True, text=True, timeout=300)
                 dt_ref = time.perf_counter() - t0
             if r.returncode == 0:
-                # the harness prints "... X s (Y Msamples/s)"; rays/sample taken from the port run
+                # the harness prints "rays N" (its own count of hitFromList calls, taken by the linker's --wrap around the
+                # unmodified reference) and "... X s (Y Msamples/s)"; an older binary without the count falls back to the
+                # port's rays per sample (same workload, same estimator: they agree to <1%) and says so
                 sec = float(r.stderr.split(":")[-1].split("s")[0])
-                rays_ref = rays   # same workload, same estimator: rays per sample agree to <1%
+                counted = [ln for ln in r.stderr.splitlines() if ln.startswith("rays ")]
+                rays_ref = int(counted[0].split()[1]) if counted else rays
                 out = dict(value=rays_ref / sec / 1e6, unit="Mrays/s", cores=1, kind="reference",
-                           sample=port["sample"].replace(f"{dt:.2f}s", f"{sec:.2f}s") + "; reference calc.cpp/hitPosition.cpp "
-                           "compiled unmodified (oracle/_ref), rays/sample from the port run",
-                           port=dict(value=port["value"], cores=1), all_cores=port["all_cores"])
+                           sample=f"{wl['scene']} scene {sw}x{sh} {sspp}spp depth{wl['depth']} ({rays_ref} rays, {sec:.2f}s)"
+                           "; reference calc.cpp/hitPosition.cpp compiled unmodified (oracle/_ref), rays = "
+                           + ("its own hitFromList calls" if counted else "rays/sample of the port run"),
+                           port=dict(value=port["value"], cores=1, rays=rays), all_cores=port["all_cores"])
         except Exception as e:   # the reference binary is optional on the GPU box
             out["reference_error"] = str(e)[:200]
     return out

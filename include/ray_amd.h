@@ -145,6 +145,13 @@ int rt_device_info(char* buf, int buflen);
 /* device memory helpers for hosts that have no allocator of their own                               */
 int rt_malloc(void** d_ptr, uint64_t bytes);
 int rt_free(void* d_ptr);
+/* Page-locked HOST memory that the device reads and writes in place (over the host link): the pointer is valid on both sides and
+ * may be passed wherever a d_* pointer is expected. For callers that trace a few rays per call (calc::ray_color with the reference's
+ * signature, ray_amd/host/ray_amd_host.h): rays in, results out, no copy calls -- the host sees what a kernel wrote once the call that
+ * launched it has returned (or rt_sync() after RT_RENDER_NOWAIT). Not for frames: every access crosses the link. No counterpart in
+ * the reference.                                                                                     */
+int rt_malloc_host(void** ptr, uint64_t bytes);
+int rt_free_host(void* ptr);
 int rt_memcpy_d2h(void* dst, const void* d_src, uint64_t bytes);
 int rt_memcpy_h2d(void* d_dst, const void* src, uint64_t bytes);
 int rt_memset(void* d_ptr, int value, uint64_t bytes);
@@ -195,7 +202,8 @@ int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_cou
               uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
 
 /* rt_render for callers that cannot allocate device memory. NO COUNTERPART IN THE REFERENCE: it exists for
- * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc. Same arguments, same
+ * tight serving loops, harnesses that forbid hipMalloc and other code that must not allocate (the call itself still
+ * synchronises its stream and reads event times, so it is NOT capturable into a HIP graph as it stands). Same arguments, same
  * kernels and bit-identical results as rt_render, but the kernel's scratch (the tile counter and the HBM part
  * of the per-thread path stack, which rt_render keeps in buffers it allocates and grows on demand) lives in a
  * file-scope device array of the library: 44 MiB + 256 B on every GPU the library is bound to, held until the

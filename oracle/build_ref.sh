@@ -23,10 +23,17 @@ if [ ! -f "$REF/calc.cpp" ] || [ ! -d "$Q/QtGui" ]; then
     exit 0
 fi
 mkdir -p "$here/_ref"
+# the mangled name of hitFromList, for the ray counter of ref_harness.cpp (linker --wrap: no reference source is touched)
+g++ -std=c++17 -O2 -fPIC -fpermissive -w -ffp-contract=off -include memory -include vector -include algorithm -include optional \
+    -I"$REF" -I"$Q" -I"$Q/QtCore" -I"$Q/QtGui" -c "$REF/hitPosition.cpp" -o "$here/_ref/hitPosition.probe.o"
+sym="$(nm "$here/_ref/hitPosition.probe.o" | awk '$2 == "T" && $3 ~ /hitFromList/ { print $3; exit }')"
+rm -f "$here/_ref/hitPosition.probe.o"
+[ -n "$sym" ] || { echo "build_ref.sh: hitFromList not found in hitPosition.o" >&2; exit 1; }
 g++ -std=c++17 -O2 -fPIC -fpermissive -fno-access-control -w -ffp-contract=off \
     -include memory -include vector -include algorithm -include optional \
     -I"$REF" -I"$Q" -I"$Q/QtCore" -I"$Q/QtGui" \
     "$here/ref_harness.cpp" "$REF/calc.cpp" "$REF/hitPosition.cpp" \
+    -DRT_HFL_SYM="\"$sym\"" -Wl,--wrap="$sym" \
     -L"$QL" -lQt5Gui -lQt5Core -Wl,-rpath,"$QL" \
     -o "$here/_ref/ref_harness"
 echo "built $here/_ref/ref_harness"

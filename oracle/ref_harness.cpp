@@ -557,6 +557,21 @@ int cmd_primary(const char* scene, int W, int H, const char* outp) {
     return 0;
 }
 
+// Rays of a render = calls of hitFromList from calc::ray_color (calc.cpp:99). The reference is compiled unmodified, so the
+// count comes from the linker: build_ref.sh passes -Wl,--wrap=<mangled hitFromList>, which sends every call from another
+// translation unit to the __wrap_ function below and keeps the reference's definition reachable as __real_.
+#ifdef RT_HFL_SYM
+}  // namespace (the wrapper needs external linkage)
+static unsigned long long g_hit_from_list_calls = 0;
+std::optional<hit_record> rt_real_hitFromList(const std::vector<std::shared_ptr<shape>>&, const Ray&, double, double) asm("__real_" RT_HFL_SYM);
+std::optional<hit_record> rt_wrap_hitFromList(const std::vector<std::shared_ptr<shape>>& l, const Ray& r, double t0, double t1) asm("__wrap_" RT_HFL_SYM);
+std::optional<hit_record> rt_wrap_hitFromList(const std::vector<std::shared_ptr<shape>>& l, const Ray& r, double t0, double t1) {
+    ++g_hit_from_list_calls;
+    return rt_real_hitFromList(l, r, t0, t1);
+}
+namespace {
+#endif
+
 // Full-frame render in row-major pixel order with the per-pixel contract of
 // RayView::renderOneRay (rayview.cpp:79-84), RNG seeded (a,b,c).
 int cmd_render(const char* scene, int W, int H, int spp, int depth, unsigned a, unsigned b, unsigned c,
@@ -578,6 +593,9 @@ int cmd_render(const char* scene, int W, int H, int spp, int depth, unsigned a, 
             push3(img, sum);
         }
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+#ifdef RT_HFL_SYM
+    fprintf(stderr, "rays %llu\n", g_hit_from_list_calls);   // before the timing line, whose last field bench.py parses
+#endif
     fprintf(stderr, "render %dx%d spp=%d depth=%d: %.3f s (%.3f Msamples/s)\n", W, H, spp, depth, sec,
             1e-6 * W * H * spp / sec);
     if (outp) {

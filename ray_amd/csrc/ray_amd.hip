@@ -314,6 +314,11 @@ __device__ __forceinline__ Hit closest_hit_listorder(const DevScene& sc, const R
 __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r, double t_min, Hit& h, uint32_t* words, bool& redo RT_STAMP_PARAM) {
     const FilterGroup& tg = sc.tg;
     if (tg.n_epairs == 0 && tg.n_fpairs == 0) return;
+    // The lanes that test an item for its owner (walk_queue) take the owner's range as FLOATS, rounded outwards, and a cell keeps
+    // only the smallest key: with a t_min that is no float (rt_hit_rays / shape::hit with any double; the render path's is
+    // double(0.001f)), a hit at rd(t_min) <= t < t_min would take the cell and hide the valid hit behind it. Such rays take the
+    // list-order scan.
+    if (double(float(t_min)) != t_min) { redo = true; return; }
     auto visit = [&](int item) {       // an item: up to two triangles under one bounding sphere
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
@@ -1875,6 +1880,13 @@ int rt_device_info(char* buf, int buflen) {
 
 int rt_malloc(void** d_ptr, uint64_t bytes) { if (need_ready()) return 1; HIP_OK(hipMalloc(d_ptr, bytes ? bytes : 1)); return 0; }
 int rt_free(void* d_ptr) { if (need_ready()) return 1; HIP_OK(hipFree(d_ptr)); return 0; }
+int rt_malloc_host(void** ptr, uint64_t bytes) {
+    if (need_ready()) return 1;
+    if (!ptr) return fail("rt_malloc_host: null argument");
+    HIP_OK(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));   // coherent, mapped into every device's address space
+    return 0;
+}
+int rt_free_host(void* ptr) { if (need_ready()) return 1; HIP_OK(hipHostFree(ptr)); return 0; }
 int rt_memcpy_d2h(void* dst, const void* d_src, uint64_t bytes) {
     if (need_ready()) return 1;
     if (settle()) return 1;

@@ -9,6 +9,13 @@
 //                                      OUT: frame[7][3] f4, lens_radius f8, ray_o[N][3], ray_d[N][3], dl2[N]
 //   mirror_kat tone N IN OUT           IN: rgb[N][3] f4, n[N] i4   OUT: rgbPerSamples [N][3] f4
 //   mirror_kat optics N IN OUT         IN: d[N][3], n[N][3] f4, eta[N] f8   OUT: reflect[N][3], refract[N][3] (of d.normalized())
+//   mirror_kat shapehits N IN OUT      IN: kind[N] i4 (0 sphere, 1 xy, 2 xz, 3 yz), prm[N][5] f8, o[N][3], d[N][3] f4, tmax[N] f8
+//                                      OUT: shape::hit_host(Ray, 0.001, tmax): has[N] u1, t[N] f8, p[N][3], n[N][3] f4, ff[N] u1, uv[N][2] f8
+//   mirror_kat shapehits_dev N IN OUT  the same through shape::hit (the one mode here that needs the GPU: one upload and one launch per shape)
+//   mirror_kat materials N IN OUT      the call sequence of oracle/ref_harness.cpp cmd_materials on engines seeded (21, 22, 23).
+//                                      IN: d, n, p [N][3] f4, ff[N] u1, prm[N][5] f4 (fuzz, albedo, -), ir[N] f8, sd[N][3] f4, pr[N][3] f4
+//                                      OUT: metal o, d, att; dielectric d, att; lambertian att [N][3] f4; spdf, cos_val [N] f8; cos_gen;
+//                                      then per light (sphere, xz, xy, yz): gen [N][3] f4, val [N] f8; mix_gen [N][3] f4, mix_val [N] f8
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,6 +24,7 @@
 
 #include <calc.h>
 #include <camera.h>
+#include <shapes.h>
 
 static std::vector<char> slurp(const char* path) {
     FILE* f = fopen(path, "rb");
@@ -105,6 +113,91 @@ int main(int argc, char** argv) {
         Out o(argv[4]);
         for (size_t i = 0; i < n; ++i) o.v3(calc::reflect(at3(d, i).normalized(), at3(nn, i)));
         for (size_t i = 0; i < n; ++i) o.v3(calc::refract(at3(d, i).normalized(), at3(nn, i), eta[i]));
+    } else if (c == "shapehits" || c == "shapehits_dev") {
+        const bool on_device = c == "shapehits_dev";   // shape::hit: the device's closest-hit kernel, u and v filled in on the host
+        const size_t n = size_t(atol(argv[2]));
+        const auto in = slurp(argv[3]);
+        const char* q = in.data();
+        const int32_t* kind = reinterpret_cast<const int32_t*>(q); q += 4 * n;
+        const double* prm = reinterpret_cast<const double*>(q); q += 40 * n;
+        const float* ro = reinterpret_cast<const float*>(q); q += 12 * n;
+        const float* rdv = reinterpret_cast<const float*>(q); q += 12 * n;
+        const double* tmax = reinterpret_cast<const double*>(q);
+        std::vector<std::optional<hit_record>> recs;
+        const std::shared_ptr<material> grey = std::make_shared<lambertian>(QVector3D(0.5, 0.5, 0.5));   // a world shape needs one to be uploaded
+        for (size_t i = 0; i < n; ++i) {
+            const double* m = prm + 5 * i;
+            std::shared_ptr<shape> sh;
+            if (kind[i] == 0) sh = std::make_shared<sphere>(QVector3D(float(m[0]), float(m[1]), float(m[2])), float(m[3]), grey);
+            else if (kind[i] == 1) sh = std::make_shared<rectangle>(m[0], m[1], m[2], m[3], m[4], grey);
+            else if (kind[i] == 2) sh = std::make_shared<xz_rect>(m[0], m[1], m[2], m[3], m[4], grey);
+            else sh = std::make_shared<yz_rect>(m[0], m[1], m[2], m[3], m[4], grey);
+            const Ray r(at3(ro, i), at3(rdv, i));
+            recs.push_back(on_device ? sh->hit(r, 0.001, tmax[i]) : sh->hit_host(r, 0.001, tmax[i]));
+        }
+        Out o(argv[4]);
+        for (auto& r : recs) { uint8_t h = r.has_value(); fwrite(&h, 1, 1, o.f); }
+        for (auto& r : recs) o.f8(r ? r->t : 0.0);
+        for (auto& r : recs) o.v3(r ? r->p : QVector3D());
+        for (auto& r : recs) o.v3(r ? r->normal : QVector3D());
+        for (auto& r : recs) { uint8_t h = r && r->front_face; fwrite(&h, 1, 1, o.f); }
+        for (auto& r : recs) { o.f8(r ? r->u : 0.0); o.f8(r ? r->v : 0.0); }
+    } else if (c == "materials") {
+        const size_t n = size_t(atol(argv[2]));
+        const auto in = slurp(argv[3]);
+        const char* q = in.data();
+        const float* d = reinterpret_cast<const float*>(q); q += 12 * n;
+        const float* nn = reinterpret_cast<const float*>(q); q += 12 * n;
+        const float* pp = reinterpret_cast<const float*>(q); q += 12 * n;
+        const uint8_t* ff = reinterpret_cast<const uint8_t*>(q); q += n;
+        const float* prm = reinterpret_cast<const float*>(q); q += 20 * n;
+        const double* ir = reinterpret_cast<const double*>(q); q += 8 * n;
+        const float* sdv = reinterpret_cast<const float*>(q); q += 12 * n;
+        const float* prv = reinterpret_cast<const float*>(q);
+        std::shared_ptr<shape> lightS = std::make_shared<sphere>(QVector3D(190, 90, 190), 90, nullptr);      // rayview.cpp:49
+        std::shared_ptr<shape> lightXZ = std::make_shared<xz_rect>(213, 343, 227, 332, 554, nullptr);
+        std::shared_ptr<shape> lightXY = std::make_shared<rectangle>(3, 5, 1, 3, -2, nullptr);
+        std::shared_ptr<shape> lightYZ = std::make_shared<yz_rect>(0, 2, 0, 2, 5, nullptr);
+        std::vector<QVector3D> met_o, met_d, met_a, die_d, die_a, lam_a, cos_gen, gen[4], mix_gen;
+        std::vector<double> spdf, cos_val, val[4], mix_val;
+        calc::gen.seed(21); calc::gen01.seed(22); calc::gen11.seed(23);
+        for (size_t i = 0; i < n; ++i) {
+            const QVector3D dir = at3(d, i), p = at3(pp, i), sd = at3(sdv, i), pr = at3(prv, i);
+            const QVector3D alb(prm[5 * i + 1], prm[5 * i + 2], prm[5 * i + 3]);
+            hit_record rec;
+            rec.p = p; rec.normal = at3(nn, i); rec.front_face = ff[i] != 0; rec.t = 1.0; rec.u = 0; rec.v = 0;
+            const Ray rin(p - dir, dir);
+            { metal m(alb, prm[5 * i]); scatter_record s; m.scatter(rin, rec, s);
+              met_o.push_back(s.specular_ray.pointOfOrigin); met_d.push_back(s.specular_ray.direction); met_a.push_back(s.attenuation); }
+            { dielectric m(ir[i]); scatter_record s; m.scatter(rin, rec, s);
+              die_d.push_back(s.specular_ray.direction); die_a.push_back(s.attenuation); }
+            { lambertian m(alb); scatter_record s; m.scatter(rin, rec, s);
+              lam_a.push_back(s.attenuation);
+              spdf.push_back(m.scattering_pdf(rin, rec, Ray(p, sd)));
+              cos_val.push_back(s.pdf_ptr->value(sd));
+              cos_gen.push_back(s.pdf_ptr->generate());
+              hittable_pdf hs(lightS, p);
+              const QVector3D gs = hs.generate();
+              gen[0].push_back(gs); val[0].push_back(hs.value(i % 2 ? gs : sd));
+              hittable_pdf hr(lightXZ, pr);
+              const QVector3D gr = hr.generate();
+              gen[1].push_back(gr); val[1].push_back(hr.value(i % 2 ? gr : sd));
+              hittable_pdf hxy(lightXY, p);
+              gen[2].push_back(hxy.generate()); val[2].push_back(hxy.value(i % 2 ? QVector3D(4, 2, -2) - p : sd));
+              hittable_pdf hyz(lightYZ, p);
+              gen[3].push_back(hyz.generate()); val[3].push_back(hyz.value(sd));
+              mixture_pdf mp(&hs, s.pdf_ptr.get());
+              const QVector3D gm = mp.generate();
+              mix_gen.push_back(gm); mix_val.push_back(mp.value(gm)); }
+        }
+        Out o(argv[4]);
+        for (auto* v : {&met_o, &met_d, &met_a, &die_d, &die_a, &lam_a}) for (auto& x : *v) o.v3(x);
+        for (double x : spdf) o.f8(x);
+        for (double x : cos_val) o.f8(x);
+        for (auto& x : cos_gen) o.v3(x);
+        for (int k = 0; k < 4; ++k) { for (auto& x : gen[k]) o.v3(x); for (double x : val[k]) o.f8(x); }
+        for (auto& x : mix_gen) o.v3(x);
+        for (double x : mix_val) o.f8(x);
     } else {
         return 2;
     }

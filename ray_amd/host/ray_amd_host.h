@@ -28,74 +28,137 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 
 namespace rt_host {
 
 // Flattens worldObjects (+ lights, background) into the arrays of RtScene and uploads them; keeps the flattened
 // list so hit records can point back at the caller's material objects. upload() returns without touching the device
-// when the flattened content is what the device already holds (content hash), so per-ray callers pay one
-// flattening pass per call, not one upload.
+// when the flattened content is, byte for byte, what the device already holds, so per-ray callers pay one
+// flattening pass per call (into buffers that keep their capacity), not one upload.
 class Session {
 public:
     explicit Session(int device = 0) : device_(device) { check(rt_init(device)); }
+    ~Session() { rt_set_device(device_); if (stage_) rt_free(stage_); if (pinned_) rt_free_host(pinned_); }
+    Session(const Session&) = delete;
     void bind() const { check(rt_set_device(device_)); }
+    // One device block that the per-ray entry points reuse for their rays and results (no rt_malloc / rt_free per call).
+    void* stage(uint64_t bytes) {
+        if (bytes > stage_bytes_) {
+            bind();
+            if (stage_) check(rt_free(stage_));
+            stage_ = nullptr; stage_bytes_ = 0;
+            const uint64_t want = bytes < 4096 ? 4096 : bytes;
+            check(rt_malloc(&stage_, want));
+            stage_bytes_ = want;
+        }
+        return stage_;
+    }
+    // The same in page-locked host memory that kernels read and write in place (rt_malloc_host): a call with a handful of rays
+    // spends its time in the copy calls otherwise.
+    void* pinned(uint64_t bytes) {
+        if (bytes > pinned_bytes_) {
+            bind();
+            if (pinned_) check(rt_free_host(pinned_));
+            pinned_ = nullptr; pinned_bytes_ = 0;
+            const uint64_t want = bytes < 4096 ? 4096 : bytes;
+            check(rt_malloc_host(&pinned_, want));
+            pinned_bytes_ = want;
+        }
+        return pinned_;
+    }
     bool upload(const std::vector<std::shared_ptr<shape>>& world, const std::shared_ptr<shape>& lights, const QVector3D& background) {
-        std::vector<flat_prim> fp;
-        std::vector<int32_t> kind, mat, outer, side;
-        std::vector<double> data;
-        std::vector<std::shared_ptr<material>> ms;
+        // Per-ray callers (calc::ray_color in a loop) come here once per ray with the same list. Every call flattens the list again --
+        // shapes and materials are the caller's objects and any member may have been written since (RayView's slider moves a centre,
+        // rayview.cpp:130-134; a freed shape's address may be reused) -- into buffers that keep their capacity, and compares the bytes
+        // with what the device holds: no allocation and no device call when nothing changed (about 10 ns per shape).
+        Flat& f = next_;
+        f.clear();
+        fp_.clear(); ms_.clear(); mat_index_.clear();
         for (size_t i = 0; i < world.size(); ++i) {
-            const size_t before = fp.size();
-            world[i]->rt_flatten(fp);
-            for (size_t j = before; j < fp.size(); ++j) {
-                const flat_prim& p = fp[j];
+            const size_t before = fp_.size();
+            world[i]->rt_flatten(fp_);
+            for (size_t j = before; j < fp_.size(); ++j) {
+                const flat_prim& p = fp_[j];
                 if (!p.mat) throw error("world shape without a material");
                 int m = -1;
-                for (size_t k = 0; k < ms.size(); ++k) if (ms[k] == p.mat) m = int(k);
-                if (m < 0) { ms.push_back(p.mat); m = int(ms.size()) - 1; }
-                kind.push_back(p.kind); mat.push_back(m); outer.push_back(int(i)); side.push_back(p.side);
-                data.insert(data.end(), p.d, p.d + RT_PRIM_STRIDE);
+                if (ms_.size() <= 8) { for (size_t k = 0; k < ms_.size(); ++k) if (ms_[k].get() == p.mat.get()) { m = int(k); break; } }
+                else { auto found = mat_index_.find(p.mat.get()); if (found != mat_index_.end()) m = found->second; }
+                if (m < 0) {
+                    m = int(ms_.size());
+                    ms_.push_back(p.mat);
+                    if (ms_.size() == 9) for (size_t k = 0; k < 8; ++k) mat_index_.emplace(ms_[k].get(), int(k));
+                    if (ms_.size() > 8) mat_index_.emplace(p.mat.get(), m);
+                }
+                f.kind.push_back(p.kind); f.mat.push_back(m); f.outer.push_back(int(i)); f.side.push_back(p.side);
+                f.data.insert(f.data.end(), p.d, p.d + RT_PRIM_STRIDE);
             }
         }
-        if (ms.empty()) ms.push_back(std::make_shared<lambertian>(QVector3D(0, 0, 0)));
-        std::vector<int32_t> mk; std::vector<float> rgb, fz; std::vector<double> ir;
-        for (auto& m : ms) {
-            mk.push_back(m->rt_kind()); QVector3D c = m->rt_rgb();
-            rgb.insert(rgb.end(), {c.x(), c.y(), c.z()}); fz.push_back(m->rt_fuzz()); ir.push_back(m->rt_ir());
+        if (ms_.empty()) ms_.push_back(std::make_shared<lambertian>(QVector3D(0, 0, 0)));
+        for (auto& m : ms_) {
+            f.mk.push_back(m->rt_kind()); QVector3D c = m->rt_rgb();
+            f.rgb.insert(f.rgb.end(), {c.x(), c.y(), c.z()}); f.fz.push_back(m->rt_fuzz()); f.ir.push_back(m->rt_ir());
         }
-        RtScene s{};
-        s.n_prims = int(kind.size());
-        s.prim_kind = kind.data(); s.prim_mat = mat.data(); s.prim_outer = outer.data(); s.prim_side = side.data();
-        s.prim_data = data.data();
-        s.n_mats = int(mk.size()); s.mat_kind = mk.data(); s.mat_rgb = rgb.data(); s.mat_fuzz = fz.data(); s.mat_ir = ir.data();
-        s.light_kind = RT_LIGHT_BASE;
+        f.light_kind = RT_LIGHT_BASE;
+        for (double& v : f.light_data) v = 0.0;
         if (lights) {
-            std::vector<flat_prim> l; lights->rt_flatten(l);
-            if (l.size() == 1 && (l[0].kind == RT_PRIM_SPHERE || l[0].kind == RT_PRIM_XY_RECT || l[0].kind == RT_PRIM_XZ_RECT)) {
-                s.light_kind = l[0].kind;
-                for (int k = 0; k < RT_PRIM_STRIDE; ++k) s.light_data[k] = l[0].d[k];
+            lt_.clear(); lights->rt_flatten(lt_);
+            if (lt_.size() == 1 && (lt_[0].kind == RT_PRIM_SPHERE || lt_[0].kind == RT_PRIM_XY_RECT || lt_[0].kind == RT_PRIM_XZ_RECT)) {
+                f.light_kind = lt_[0].kind;
+                for (int k = 0; k < RT_PRIM_STRIDE; ++k) f.light_data[k] = lt_[0].d[k];
             }   // box / yz_rect / medium lights use the base class pdf (shapes.h:56-62)
         }
-        s.background[0] = background.x(); s.background[1] = background.y(); s.background[2] = background.z();
-        uint64_t h = 1469598103934665603ull;   // FNV-1a over everything the device would receive
-        auto mix = [&h](const void* p, size_t n) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } };
-        mix(kind.data(), kind.size() * 4); mix(mat.data(), mat.size() * 4); mix(data.data(), data.size() * 8);
-        mix(mk.data(), mk.size() * 4); mix(rgb.data(), rgb.size() * 4); mix(fz.data(), fz.size() * 4); mix(ir.data(), ir.size() * 8);
-        mix(&s.light_kind, 4); mix(s.light_data, sizeof s.light_data); mix(s.background, sizeof s.background);
+        f.background[0] = background.x(); f.background[1] = background.y(); f.background[2] = background.z();
         bind();
-        const bool fresh = !have_ || h != hash_ || kind.size() != prims.size();
-        if (fresh) { check(rt_upload_scene(&s)); hash_ = h; have_ = true; ++uploads; }
-        prims.swap(fp); mats.swap(ms); outer_of.swap(outer);
+        const bool fresh = !have_ || !(f == held_);
+        if (fresh) {
+            RtScene s{};
+            s.n_prims = int(f.kind.size());
+            s.prim_kind = f.kind.data(); s.prim_mat = f.mat.data(); s.prim_outer = f.outer.data(); s.prim_side = f.side.data();
+            s.prim_data = f.data.data();
+            s.n_mats = int(f.mk.size()); s.mat_kind = f.mk.data(); s.mat_rgb = f.rgb.data(); s.mat_fuzz = f.fz.data(); s.mat_ir = f.ir.data();
+            s.light_kind = f.light_kind;
+            for (int k = 0; k < RT_PRIM_STRIDE; ++k) s.light_data[k] = f.light_data[k];
+            for (int k = 0; k < 3; ++k) s.background[k] = f.background[k];
+            have_ = false;
+            check(rt_upload_scene(&s));
+            have_ = true; ++uploads;
+            std::swap(held_, next_);
+        }
+        prims.swap(fp_); mats.swap(ms_);
         return fresh;
     }
-    std::vector<flat_prim> prims;
+    std::vector<flat_prim> prims;                     // the flattened list of the last upload() call: record -> the caller's material objects
     std::vector<std::shared_ptr<material>> mats;
-    std::vector<int32_t> outer_of;
+    const std::vector<int32_t>& outer_of() const { return held_.outer; }   // flattened primitive -> index in the caller's list
     int uploads = 0;              // how often the device copy was actually replaced
 private:
+    struct Flat {                 // everything rt_upload_scene receives
+        std::vector<int32_t> kind, mat, outer, side, mk;
+        std::vector<double> data, ir;
+        std::vector<float> rgb, fz;
+        int32_t light_kind = 0;
+        double light_data[RT_PRIM_STRIDE] = {};
+        float background[3] = {};
+        void clear() { kind.clear(); mat.clear(); outer.clear(); side.clear(); mk.clear(); data.clear(); ir.clear(); rgb.clear(); fz.clear(); }
+        template <class T> static bool same(const std::vector<T>& a, const std::vector<T>& b) {   // bytes, not values: -0.0 is not 0.0 here, and NaN is NaN
+            return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(T)) == 0);
+        }
+        bool operator==(const Flat& o) const {
+            return same(kind, o.kind) && same(mat, o.mat) && same(outer, o.outer) && same(side, o.side) && same(mk, o.mk) && same(data, o.data) && same(ir, o.ir) &&
+                   same(rgb, o.rgb) && same(fz, o.fz) && light_kind == o.light_kind && std::memcmp(light_data, o.light_data, sizeof light_data) == 0 &&
+                   std::memcmp(background, o.background, sizeof background) == 0;
+        }
+    };
     int device_;
-    uint64_t hash_ = 0;
     bool have_ = false;
+    Flat held_, next_;            // what the device holds; this call's list
+    std::vector<flat_prim> fp_, lt_;
+    std::vector<std::shared_ptr<material>> ms_;
+    std::unordered_map<const material*, int> mat_index_;
+    void* stage_ = nullptr;
+    void* pinned_ = nullptr;
+    uint64_t stage_bytes_ = 0, pinned_bytes_ = 0;
 };
 
 // The session behind the reference-signature entry points (device: $RAY_AMD_DEVICE, default 0).
@@ -114,32 +177,72 @@ struct DevBuf {
     DevBuf(const DevBuf&) = delete;
 };
 
+// hit_record::u, v (shapes.h:105,144-158 for a sphere, :183-184 / :249-250 / :315-316 for the rects) from the record the library
+// returned, with the reference's own expressions on the host (same libm as the reference: exact). The outward normal of a sphere
+// is the record's normal, flipped back when the hit was from inside (setFaceNormal only negates). Other kinds keep 0.
+inline void fill_uv(const flat_prim& fp, const Ray& ray, hit_record& rec) {
+    if (fp.kind == RT_PRIM_SPHERE) {
+        sphere::get_sphere_uv(rec.front_face ? rec.normal : -rec.normal, rec.u, rec.v);
+    } else if (fp.kind == RT_PRIM_XY_RECT || fp.kind == RT_PRIM_XZ_RECT || fp.kind == RT_PRIM_YZ_RECT) {
+        const QVector3D &o = ray.pointOfOrigin, &d = ray.direction;
+        const float oa = fp.kind == RT_PRIM_YZ_RECT ? o.y() : o.x(), da = fp.kind == RT_PRIM_YZ_RECT ? d.y() : d.x();
+        const float ob = fp.kind == RT_PRIM_XY_RECT ? o.y() : o.z(), db = fp.kind == RT_PRIM_XY_RECT ? d.y() : d.z();
+        rec.u = ((oa + rec.t * da) - fp.d[0]) / (fp.d[1] - fp.d[0]);
+        rec.v = ((ob + rec.t * db) - fp.d[2]) / (fp.d[3] - fp.d[2]);
+    }
+}
+
+// One ray against the uploaded list: ray in, record out through the session's page-locked block (one launch, no copy calls).
 inline std::optional<hit_record> hit_uploaded(Session& s, const Ray& ray, double t_min, double t_max) {
-    const float o[3] = {ray.pointOfOrigin.x(), ray.pointOfOrigin.y(), ray.pointOfOrigin.z()};
-    const float d[3] = {ray.direction.x(), ray.direction.y(), ray.direction.z()};
-    DevBuf bo(12), bd(12), bprim(4), bt(8), bp(12), bn(12), bf(1);
-    check(rt_memcpy_h2d(bo.p, o, 12)); check(rt_memcpy_h2d(bd.p, d, 12));
-    check(rt_hit_rays(1, (const float*)bo.p, (const float*)bd.p, t_min, t_max, (int32_t*)bprim.p, (double*)bt.p, (float*)bp.p, (float*)bn.p,
-                      (uint8_t*)bf.p));
-    int32_t prim; double t; float p[3], n[3]; uint8_t ff;
-    check(rt_memcpy_d2h(&prim, bprim.p, 4)); check(rt_memcpy_d2h(&t, bt.p, 8));
-    check(rt_memcpy_d2h(p, bp.p, 12)); check(rt_memcpy_d2h(n, bn.p, 12)); check(rt_memcpy_d2h(&ff, bf.p, 1));
-    if (prim < 0) return std::nullopt;
+    s.bind();
+    struct In { float o[3], d[3]; float pad[2]; };
+    struct Res { double t; float p[3], n[3]; int32_t prim; uint8_t ff; uint8_t pad[3]; };
+    char* blk = static_cast<char*>(s.pinned(sizeof(In) + sizeof(Res)));
+    In* in = reinterpret_cast<In*>(blk);
+    Res* out = reinterpret_cast<Res*>(blk + sizeof(In));
+    *in = In{{ray.pointOfOrigin.x(), ray.pointOfOrigin.y(), ray.pointOfOrigin.z()}, {ray.direction.x(), ray.direction.y(), ray.direction.z()}, {0, 0}};
+    check(rt_hit_rays(1, in->o, in->d, t_min, t_max, &out->prim, &out->t, out->p, out->n, &out->ff));
+    const Res r = *out;
+    if (r.prim < 0) return std::nullopt;
     hit_record rec;
-    rec.p = QVector3D(p[0], p[1], p[2]); rec.normal = QVector3D(n[0], n[1], n[2]); rec.t = t; rec.front_face = ff != 0;
-    rec.rt_prim = prim; rec.mat_ptr = s.prims[size_t(prim)].mat;
+    rec.p = QVector3D(r.p[0], r.p[1], r.p[2]); rec.normal = QVector3D(r.n[0], r.n[1], r.n[2]); rec.t = r.t; rec.front_face = r.ff != 0;
+    rec.rt_prim = r.prim; rec.mat_ptr = s.prims[size_t(r.prim)].mat;
+    fill_uv(s.prims[size_t(r.prim)], ray, rec);
     return rec;
 }
 
-inline QVector3D trace_uploaded(const Ray& r, int depth, bool drawOnlyColors, uint64_t seed) {
-    const float o[3] = {r.pointOfOrigin.x(), r.pointOfOrigin.y(), r.pointOfOrigin.z()};
-    const float d[3] = {r.direction.x(), r.direction.y(), r.direction.z()};
-    DevBuf bo(12), bd(12), bc(12);
-    check(rt_memcpy_h2d(bo.p, o, 12)); check(rt_memcpy_h2d(bd.p, d, 12));
-    check(rt_trace_rays(1, (const float*)bo.p, (const float*)bd.p, depth, seed, drawOnlyColors ? RT_RENDER_NORMALS : 0u, (float*)bc.p));
-    float c[3];
-    check(rt_memcpy_d2h(c, bc.p, 12));
-    return QVector3D(c[0], c[1], c[2]);
+// calc::ray_color for n rays in ONE launch: ray i draws from the counter-RNG stream (seed, i, 0) (include/ray_amd.h, rt_trace_rays)
+inline void trace_uploaded(Session& s, const Ray* rays, size_t n, int depth, bool drawOnlyColors, uint64_t seed, QVector3D* colours) {
+    if (n == 0) return;
+    s.bind();
+    const unsigned flags = drawOnlyColors ? RT_RENDER_NORMALS : 0u;
+    if (n <= 4096) {   // few rays: the kernel reads them from, and writes the colours to, page-locked host memory
+        float* blk = static_cast<float*>(s.pinned(uint64_t(9 * n) * 4));
+        for (size_t i = 0; i < n; ++i) {
+            const QVector3D &o = rays[i].pointOfOrigin, &d = rays[i].direction;
+            blk[3 * i] = o.x(); blk[3 * i + 1] = o.y(); blk[3 * i + 2] = o.z();
+            blk[3 * n + 3 * i] = d.x(); blk[3 * n + 3 * i + 1] = d.y(); blk[3 * n + 3 * i + 2] = d.z();
+        }
+        check(rt_trace_rays(int64_t(n), blk, blk + 3 * n, depth, seed, flags, blk + 6 * n));
+        for (size_t i = 0; i < n; ++i) colours[i] = QVector3D(blk[6 * n + 3 * i], blk[6 * n + 3 * i + 1], blk[6 * n + 3 * i + 2]);
+        return;
+    }
+    std::vector<float> in(6 * n), out(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        const QVector3D &o = rays[i].pointOfOrigin, &d = rays[i].direction;
+        in[3 * i] = o.x(); in[3 * i + 1] = o.y(); in[3 * i + 2] = o.z();
+        in[3 * n + 3 * i] = d.x(); in[3 * n + 3 * i + 1] = d.y(); in[3 * n + 3 * i + 2] = d.z();
+    }
+    float* blk = static_cast<float*>(s.stage(uint64_t(9 * n) * 4));
+    check(rt_memcpy_h2d(blk, in.data(), uint64_t(6 * n) * 4));
+    check(rt_trace_rays(int64_t(n), blk, blk + 3 * n, depth, seed, flags, blk + 6 * n));
+    check(rt_memcpy_d2h(out.data(), blk + 6 * n, uint64_t(3 * n) * 4));
+    for (size_t i = 0; i < n; ++i) colours[i] = QVector3D(out[3 * i], out[3 * i + 1], out[3 * i + 2]);
+}
+inline QVector3D trace_uploaded(Session& s, const Ray& r, int depth, bool drawOnlyColors, uint64_t seed) {
+    QVector3D c;
+    trace_uploaded(s, &r, 1, depth, drawOnlyColors, seed, &c);
+    return c;
 }
 
 }  // namespace rt_host
@@ -171,12 +274,22 @@ inline QVector3D ray_color(const Ray& r, const QVector3D& background, const std:
                            std::shared_ptr<shape>& lights, int depth, bool drawOnlyColors) {
     rt_host::Session& s = rt_host::default_session();
     s.upload(worldObjects, lights, background);
-    return rt_host::trace_uploaded(r, depth, drawOnlyColors, rt_host::ray_color_stream()++);
+    return rt_host::trace_uploaded(s, r, depth, drawOnlyColors, rt_host::ray_color_stream()++);
+}
+// The same for a batch of rays in one launch (not in the reference, whose caller loops over single rays, rayview.cpp:79-84): what a
+// caller that has its samples' rays at hand should use -- a launch costs the GPU tens of microseconds whether it traces one ray or
+// a hundred thousand. Ray i draws from the counter-RNG stream (k, i, 0), k = this call's number as above.
+inline std::vector<QVector3D> ray_color(const std::vector<Ray>& rays, const QVector3D& background, const std::vector<std::shared_ptr<shape>>& worldObjects,
+                                        std::shared_ptr<shape>& lights, int depth, bool drawOnlyColors = false) {
+    rt_host::Session& s = rt_host::default_session();
+    s.upload(worldObjects, lights, background);
+    std::vector<QVector3D> out(rays.size());
+    rt_host::trace_uploaded(s, rays.data(), rays.size(), depth, drawOnlyColors, rt_host::ray_color_stream()++, out.data());
+    return out;
 }
 // against an explicitly managed session whose scene is already uploaded; `seed` selects the counter-RNG stream
 inline QVector3D ray_color(rt_host::Session& s, const Ray& r, int depth, bool drawOnlyColors = false, uint64_t seed = 0) {
-    s.bind();
-    return rt_host::trace_uploaded(r, depth, drawOnlyColors, seed);
+    return rt_host::trace_uploaded(s, r, depth, drawOnlyColors, seed);
 }
 }  // namespace calc
 

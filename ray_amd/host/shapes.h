@@ -1,7 +1,10 @@
 // Mirror of the reference's shapes.h: aabb, shape, sphere, rectangle, xz_rect, yz_rect, box, constant_medium with
 // the reference's constructors and public members. A shape DESCRIBES geometry to the HIP library
 // (rt_flatten -> RtScene, include/ray_amd.h); shape::hit forwards to the library like hitFromList does.
-// bounding_box / aabb are host arithmetic as in the reference (shapes.h:14-44 and the *_output_box members).
+// bounding_box / aabb are host arithmetic as in the reference (shapes.h:14-44 and the *_output_box members), and so
+// are shape::pdf_value / random (shapes.h:56-62,117-135,202-219,268-284), the light-sampling half of hittable_pdf:
+// they ask one shape about one ray (hit_host: sphere::hit / the rect hits restated for the host, shapes.h:77-109,
+// 172-192,238-258,304-323), which is no work for a GPU. Pinned by tests/golden/{shapehits,materials}.npz (mirror_kat).
 #ifndef SHAPES_H
 #define SHAPES_H
 #ifndef RAY_AMD_MIRROR_OUTER   // the header the translation unit included itself pulls in ray_amd_host.h at its end
@@ -52,6 +55,10 @@ struct shape {                                                        // shapes.
     // one ray against this shape alone, on the GPU (definition: ray_amd_host.h)
     virtual std::optional<hit_record> hit(const Ray& r, double t_min, double t_max) const;
     virtual bool bounding_box(aabb& output_box) const = 0;
+    virtual double pdf_value(const QVector3D&, const QVector3D&) const { return 0.0; }              // shapes.h:56-58
+    virtual QVector3D random(const QVector3D&) const { return QVector3D(1, 0, 0); }                  // shapes.h:60-62
+    // the reference's own hit arithmetic for this ONE shape, on the host (what pdf_value needs); shapes without one: no hit
+    virtual std::optional<hit_record> hit_host(const Ray&, double, double) const { return std::nullopt; }
     virtual void rt_flatten(std::vector<rt_host::flat_prim>& out) const = 0;
     QVector3D center;   // mutable, as RayView's slider does (rayview.cpp:130-134)
 };
@@ -62,6 +69,48 @@ struct sphere : public shape {                                        // shapes.
     bool bounding_box(aabb& output_box) const override { output_box = aabb(center - radded, center + radded); return true; }
     void rt_flatten(std::vector<rt_host::flat_prim>& out) const override {
         out.push_back({RT_PRIM_SPHERE, {center.x(), center.y(), center.z(), radius}, mat, -1});
+    }
+    std::optional<hit_record> hit_host(const Ray& ray, double t_min, double t_max) const override {   // shapes.h:77-109
+        const QVector3D oc = ray.pointOfOrigin - center;
+        const float a = ray.DirlengthSquared;
+        const float b = QVector3D::dotProduct(oc, ray.direction);
+        const float c = oc.lengthSquared() - radiusSquared;
+        const float d = b * b - a * c;
+        if (d < 0.0) return {};
+        const double sqrtd = std::sqrt(double(d));
+        double root = (-b - sqrtd) / a;
+        if (root < t_min || t_max < root) {
+            root = (-b + sqrtd) / a;
+            if (root < t_min || t_max < root) return {};
+        }
+        hit_record rec;
+        rec.t = root;
+        rec.p = ray.at(root);
+        rec.mat_ptr = mat;
+        const QVector3D outward = (rec.p - center) / radius;
+        get_sphere_uv(outward, rec.u, rec.v);
+        rec.setFaceNormal(ray, outward);
+        return rec;
+    }
+    double pdf_value(const QVector3D& o, const QVector3D& v) const override {                          // shapes.h:117-127
+        if (!hit_host(Ray(o, v), 0.001, calc::infinity).has_value()) return 0.0;
+        const double cos_theta_max = std::sqrt(double(1 - radius * radius / (center - o).lengthSquared()));
+        const double solid_angle = 2 * calc::pi * (1 - cos_theta_max);
+        return 1 / solid_angle;
+    }
+    QVector3D random(const QVector3D& o) const override {                                              // shapes.h:129-135
+        const QVector3D direction = center - o;
+        const float distance_squared = direction.lengthSquared();
+        onb uvw;
+        uvw.build_from_w(direction);
+        return uvw.local(calc::random_to_sphere(radius, distance_squared));
+    }
+    // shapes.h:144-158: p a point of the unit sphere; u the angle around Y from X = -1, v the angle from Y = -1, both in [0, 1]
+    static void get_sphere_uv(const QVector3D& p, double& u, double& v) {
+        const double theta = std::acos(double(-p.y()));
+        const double phi = std::atan2(double(-p.z()), double(p.x())) + calc::pi;
+        u = phi / (2.0f * calc::pi);
+        v = theta / calc::pi;
     }
     const float radius;
     const QVector3D radded;
@@ -81,13 +130,64 @@ struct rect_base : public shape {
         else output_box = aabb(QVector3D(float(q[4] - 0.0001), a0, b0), QVector3D(float(q[4] + 0.0001), a1, b1));
         return true;
     }
+    // shapes.h:172-192, 238-258, 304-323: the plane distance and the in-plane point in double (k and the bounds are doubles)
+    std::optional<hit_record> hit_host(const Ray& r, double t_min, double t_max) const override {
+        const QVector3D &o = r.pointOfOrigin, &d = r.direction;
+        const float ok = KIND == RT_PRIM_XY_RECT ? o.z() : (KIND == RT_PRIM_XZ_RECT ? o.y() : o.x());
+        const float dk = KIND == RT_PRIM_XY_RECT ? d.z() : (KIND == RT_PRIM_XZ_RECT ? d.y() : d.x());
+        const float oa = KIND == RT_PRIM_YZ_RECT ? o.y() : o.x(), da = KIND == RT_PRIM_YZ_RECT ? d.y() : d.x();
+        const float ob = KIND == RT_PRIM_XY_RECT ? o.y() : o.z(), db = KIND == RT_PRIM_XY_RECT ? d.y() : d.z();
+        const double t = (q[4] - ok) / dk;
+        if (t < t_min || t > t_max) return {};
+        const double a = oa + t * da, b = ob + t * db;
+        if (a < q[0] || a > q[1] || b < q[2] || b > q[3]) return {};
+        hit_record rec;
+        rec.u = (a - q[0]) / (q[1] - q[0]);
+        rec.v = (b - q[2]) / (q[3] - q[2]);
+        rec.t = t;
+        rec.setFaceNormal(r, KIND == RT_PRIM_XY_RECT ? RectangleNormal::xy : (KIND == RT_PRIM_XZ_RECT ? RectangleNormal::xz : RectangleNormal::yz));
+        rec.mat_ptr = mp;
+        rec.p = r.at(t);
+        return rec;
+    }
+    // shapes.h:202-219, 268-284 (rectangle and xz_rect; yz_rect has neither and keeps the base class's 0 and (1, 0, 0))
+    double pdf_value(const QVector3D& origin, const QVector3D& v) const override {
+        if (KIND == RT_PRIM_YZ_RECT) return 0.0;
+        const auto h = hit_host(Ray(origin, v), 0.001, calc::infinity);
+        if (!h.has_value()) return 0.0;
+        const double area = (q[1] - q[0]) * (q[3] - q[2]);
+        const double distance_squared = h->t * h->t * v.lengthSquared();
+        const double cosine = std::fabs(double(QVector3D::dotProduct(v, h->normal) / v.length()));
+        return distance_squared / (cosine * area);
+    }
+    QVector3D random(const QVector3D& origin) const override {
+        if (KIND == RT_PRIM_YZ_RECT) return QVector3D(1, 0, 0);
+        // QVector3D(random_double(a0, a1), k, random_double(b0, b1)) - origin for BOTH kinds: the reference's XY rectangle also puts k
+        // in the y slot; its binary (g++) evaluates the constructor's arguments right to left, so the (b0, b1)
+        // draw comes first (pinned by tests/golden/materials.npz)
+        const float second = calc::random_double(float(q[2]), float(q[3]));
+        const float first = calc::random_double(float(q[0]), float(q[1]));
+        return QVector3D(first, float(q[4]), second) - origin;
+    }
     std::shared_ptr<material> mp;
     const double q[5];   // (x0, x1, y0, y1, k) / (x0, x1, z0, z1, k) / (y0, y1, z0, z1, k)
 };
 }  // namespace rt_host
-struct rectangle : public rt_host::rect_base<RT_PRIM_XY_RECT> { using rect_base::rect_base; };                 // shapes.h:161-224
-class xz_rect : public rt_host::rect_base<RT_PRIM_XZ_RECT> { public: using rect_base::rect_base; };            // shapes.h:226-290
-class yz_rect : public rt_host::rect_base<RT_PRIM_YZ_RECT> { public: using rect_base::rect_base; };            // shapes.h:292-337
+// the reference's public members by their names (shapes.h:222, 288, 335)
+struct rectangle : public rt_host::rect_base<RT_PRIM_XY_RECT> {                                                // shapes.h:161-224
+    using rect_base::rect_base;
+    const double &x0 = q[0], &x1 = q[1], &y0 = q[2], &y1 = q[3], &k = q[4];
+};
+class xz_rect : public rt_host::rect_base<RT_PRIM_XZ_RECT> {                                                   // shapes.h:226-290
+public:
+    using rect_base::rect_base;
+    const double &x0 = q[0], &x1 = q[1], &z0 = q[2], &z1 = q[3], &k = q[4];
+};
+class yz_rect : public rt_host::rect_base<RT_PRIM_YZ_RECT> {                                                   // shapes.h:292-337
+public:
+    using rect_base::rect_base;
+    const double &y0 = q[0], &y1 = q[1], &z0 = q[2], &z1 = q[3], &k = q[4];
+};
 
 class box : public shape {                                            // shapes.h:339-372
 public:
@@ -150,6 +250,10 @@ struct triangle : public shape {
     QVector3D v0, v1, v2;
     std::shared_ptr<material> mat;
 };
+
+// hitPosition.cpp:55-61
+inline double hittable_pdf::value(const QVector3D& direction) const { return ptr->pdf_value(o, direction); }
+inline QVector3D hittable_pdf::generate() const { return ptr->random(o); }
 
 // hitPosition.cpp:24-53
 inline aabb surrounding_box(aabb box0, aabb box1) {

@@ -72,3 +72,36 @@ def test_scene_flattening_box_order_and_text_roundtrip():
     assert txt.count("\nbox ") == 26 and "light xz_rect" in txt
     assert scenes.random_scene(11).flatten()["n_prims"] in range(470, 490)
     assert scenes.tri_mesh_scene().flatten()["n_prims"] == 9800 + 2
+
+
+def test_two_context_objects_each_reach_their_own_device():
+    """The C library keeps one context per GPU and acts on the calling thread's CURRENT one, so api.Context rebinds its device before
+    every call. Checked here without a GPU: a stand-in library that records (current device, call) pairs must see every call
+    of each object arrive with that object's device current, however the calls of two objects interleave, close() included."""
+    from ray_amd import api
+
+    class FakeLib:
+        def __init__(self):
+            self.current, self.log = None, []
+
+        def rt_set_device(self, d):
+            self.current = d
+            return 0
+
+        def rt_last_error(self):
+            return b""
+
+        def __getattr__(self, name):
+            def fn(*args):
+                self.log.append((self.current, name))
+                return 0
+            return fn
+
+    fake = FakeLib()
+    a, b = api.Context.__new__(api.Context), api.Context.__new__(api.Context)
+    for obj, dev in ((a, 0), (b, 1)):
+        obj.lib, obj.device, obj._scene_keep = api._BoundLib(fake, dev), dev, None
+    a.sync(); b.sync(); a.set_sample_slices(4, 2); b.set_tail_limit(7); a.last_kernel_ms(); b.last_kernel_ms()
+    b.close(); a.sync(); a.close()
+    assert fake.log == [(0, "rt_sync"), (1, "rt_sync"), (0, "rt_set_sample_slices"), (1, "rt_set_tail_limit"), (0, "rt_last_kernel_ms"),
+                        (1, "rt_last_kernel_ms"), (1, "rt_shutdown"), (0, "rt_sync"), (0, "rt_shutdown")]

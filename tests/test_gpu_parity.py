@@ -634,6 +634,7 @@ def test_triangle_known_answers_on_the_gpu(rt):
     for seed in (5, 6, 7):
         tri_kat.check_general_triangles(hit_rays, seed=seed)
     tri_kat.check_triangle_pair_equals_rectangle(hit_rays)
+    tri_kat.check_t_min_that_is_no_float(hit_rays)
 
 
 def test_render_pixels_duplicates_accumulate_and_stray_indices(rt):
@@ -820,6 +821,41 @@ def test_reference_signature_caller_renderOneRay(rt, tmp_path):
     tone = np.empty((2 * ticks, 3), np.float32)
     O.lib().orc_tonemap(2 * ticks, O.P(np.ascontiguousarray(t["sum"]), C.c_float), O.P(np.full(2 * ticks, spp, np.int32), C.c_int32), O.P(tone, C.c_float))
     assert O.same_values(t["px"], tone)
+
+
+def test_shape_hit_on_the_device_fills_u_v_like_the_reference(tmp_path):
+    """shape::hit of the mirror headers (device closest-hit kernel, then hit_record::u, v on the host as sphere::get_sphere_uv and the
+    rects' (x - x0) / (x1 - x0) compute them) on every 97th case of tests/golden/shapehits.npz -- the compiled reference's own
+    sphere::hit / xy/xz/yz_rect::hit outputs: has, t, p, normal, front_face, u, v bit for bit."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ray_amd", "host", "mirror_kat")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    g = O.golden("shapehits")
+    step = 97    # prime against the period of the case generator (every 100th rect case is a miss)
+    for pre, kind, prm in (("sph", np.zeros(24000, np.int32), np.pad(g["sph_prm"].astype(np.float64), ((0, 0), (0, 1)))),
+                           ("rect", (g["rect_axis"] + 1).astype(np.int32), g["rect_prm"])):
+        sel = np.arange(0, kind.shape[0], step)
+        n = sel.shape[0]
+        with open(tmp_path / "in.bin", "wb") as f:
+            for a in (kind, prm, g[pre + "_ray_o"], g[pre + "_ray_d"], g[pre + "_tmax"]):
+                f.write(np.ascontiguousarray(a[sel]).tobytes())
+        r = subprocess.run([exe, "shapehits_dev", str(n), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stderr
+        b, pos = np.fromfile(tmp_path / "out.bin", np.uint8), 0
+
+        def take(dtype, shape):
+            nonlocal pos
+            k = int(np.prod(shape)) * np.dtype(dtype).itemsize
+            out = b[pos:pos + k].view(dtype).reshape(shape)
+            pos += k
+            return out
+        has, t, pp, nrm, ff, uv = take(np.uint8, (n,)), take(np.float64, (n,)), take(np.float32, (n, 3)), take(np.float32, (n, 3)), take(np.uint8, (n,)), take(np.float64, (n, 2))
+        assert np.array_equal(has, g[pre + "_has"][sel]) and 0.05 < has.mean() < 0.95, pre
+        h = has.astype(bool)
+        assert O.bits_equal(t[h], g[pre + "_t"][sel][h]) and O.bits_equal(pp[h], g[pre + "_p"][sel][h]) and O.bits_equal(nrm[h], g[pre + "_n"][sel][h]), pre
+        assert np.array_equal(ff[h], g[pre + "_ff"][sel][h]) and O.bits_equal(uv[h], g[pre + "_uv"][sel][h]), pre
 
 
 @pytest.mark.parametrize("split,shares", [("spp", 3), ("tile", 3), ("tile", 8), ("spp", 1)])

@@ -100,3 +100,52 @@ def test_a_caller_shaped_like_renderOneRay_compiles_against_the_mirror_headers(t
                         os.path.join(ROOT, "include"), src, "-o", str(tmp_path / "tick"), "-L", csrc, "-lray_amd", "-Wl,-rpath," + csrc],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+def test_host_hit_arithmetic_and_uv_match_the_reference(kat):
+    """shape::hit_host (what shape::pdf_value asks one shape about one ray) and hit_record::u, v (get_sphere_uv, the rects' (x - x0) /
+    (x1 - x0)): the 48k sphere and rect cases of the compiled reference, incl. tangent, inside, on-surface, edge and axis-parallel rays."""
+    g = O.golden("shapehits")
+    for pre, kind, prm in (("sph", np.zeros(24000, np.int32), np.pad(g["sph_prm"].astype(np.float64), ((0, 0), (0, 1)))),
+                           ("rect", (g["rect_axis"] + 1).astype(np.int32), g["rect_prm"])):
+        n = kind.shape[0]
+        b, pos = kat("shapehits", n, inputs=[kind, prm, g[pre + "_ray_o"], g[pre + "_ray_d"], g[pre + "_tmax"]]), 0
+        has, pos = _take(b, pos, np.uint8, (n,))
+        t, pos = _take(b, pos, np.float64, (n,))
+        p, pos = _take(b, pos, np.float32, (n, 3))
+        nrm, pos = _take(b, pos, np.float32, (n, 3))
+        ff, pos = _take(b, pos, np.uint8, (n,))
+        uv, pos = _take(b, pos, np.float64, (n, 2))
+        assert np.array_equal(has, g[pre + "_has"]) and 0.05 < has.mean() < 0.95
+        h = has.astype(bool)
+        assert O.bits_equal(t[h], g[pre + "_t"][h]) and O.bits_equal(p[h], g[pre + "_p"][h]) and O.bits_equal(nrm[h], g[pre + "_n"][h])
+        assert np.array_equal(ff[h], g[pre + "_ff"][h]) and O.bits_equal(uv[h], g[pre + "_uv"][h])
+
+
+def test_material_and_pdf_classes_match_the_reference(kat):
+    """material::scatter / scattering_pdf, onb, cosine_pdf, hittable_pdf over a sphere / XZ / XY (quirk Q2) / YZ (base class) light,
+    mixture_pdf, shape::pdf_value / random: the 4000-case call sequence of the compiled reference on engines seeded (21, 22, 23),
+    replayed through the mirror headers' host arithmetic."""
+    g = O.golden("materials")
+    n = g["in_d"].shape[0]
+    assert tuple(g["seeds"]) == (21, 22, 23)
+    pr = np.ascontiguousarray(g["xzlight_gen_and_o"][:, 1])
+    b, pos = kat("materials", n, inputs=[g["in_d"], g["in_n"], g["in_p"], g["in_ff"], g["prm"], g["ir"], g["lamb_sd"], pr]), 0
+    for key in ("metal_o", "metal_d", "metal_att", "diel_d", "diel_att", "lamb_att"):
+        got, pos = _take(b, pos, np.float32, (n, 3))
+        assert O.bits_equal(got, g[key]), key
+    for key in ("lamb_spdf", "cos_val"):
+        got, pos = _take(b, pos, np.float64, (n,))
+        assert O.bits_equal(got, g[key]), key
+    got, pos = _take(b, pos, np.float32, (n, 3))
+    assert O.bits_equal(got, g["cos_gen"])
+    for light in ("sphlight", "xzlight", "xylight", "yzlight"):
+        gen, pos = _take(b, pos, np.float32, (n, 3))
+        val, pos = _take(b, pos, np.float64, (n,))
+        want = g[light + "_gen_and_o"][:, 0] if light == "xzlight" else g[light + "_gen"]
+        assert O.bits_equal(gen, want), light
+        assert O.same_bits_or_nan(val, g[light + "_val"]), light
+    gen, pos = _take(b, pos, np.float32, (n, 3))
+    val, pos = _take(b, pos, np.float64, (n,))
+    assert O.bits_equal(gen, g["mix_gen"]) and O.same_bits_or_nan(val, g["mix_val"])
+    assert (g["sphlight_val"] > 0).mean() > 0.3 and (g["xzlight_val"] > 0).mean() > 0.3

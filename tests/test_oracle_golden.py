@@ -298,6 +298,7 @@ def test_triangle_known_answers():
     for seed in (5, 6):
         tri_kat.check_general_triangles(O.hit_rays, seed=seed)
     tri_kat.check_triangle_pair_equals_rectangle(O.hit_rays)
+    tri_kat.check_t_min_that_is_no_float(O.hit_rays)
 
 
 # ---- constant_medium::hit (shapes.h:374-455) ---------------------------------------------------------------

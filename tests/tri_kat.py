@@ -154,3 +154,22 @@ def check_triangle_pair_equals_rectangle(hit_rays, seed=9, n=3000):
     assert np.array_equal((pa >= 0)[clear], (pb >= 0)[clear]) and h.sum() > n // 10
     assert np.allclose(ta[h], tb[h], rtol=1e-5, atol=0) and np.allclose(ppa[h], ppb[h], rtol=1e-5, atol=1e-5)
     assert np.array_equal(na[h], nb[h]) and np.array_equal(fa[h], fb[h])
+
+
+def check_t_min_that_is_no_float(hit_rays):
+    """40 stacked unit triangles at z = 0, -1, -2, ... and rays straight down from z = 1: hits at t = 1, 2, 3, ... exactly.
+    With t_min one part in 2^30 above 1 (a double that is no float: it rounds DOWN to 1.0f) the hit at t = 1 is outside the range
+    and the triangle behind it, at t = 2, must be reported (the triangle queue's workers test against the owner's range
+    as floats; a hit at rd(t_min) must not hide the valid one behind it). 40 triangles: enough for the filter group and its queue."""
+    shapes = [scenes.Shape("triangle", (0.0, 0.0, -float(k), 1.0, 0.0, -float(k), 0.0, 1.0, -float(k)), 0) for k in range(40)]
+    sc = _scene(shapes)
+    n = 70                                                             # more rays than a wave
+    ro = np.tile(np.array([[0.25, 0.25, 1.0]], np.float32), (n, 1))
+    ro[:, 0] += np.arange(n, dtype=np.float32) / 256.0                 # exact in FP32, all inside the triangles
+    rd = np.tile(np.array([[0.0, 0.0, -1.0]], np.float32), (n, 1))
+    for t_min, t_max, want_prim, want_t in ((1.0 + 2.0 ** -30, INF, 1, 2.0), (1.0, INF, 0, 1.0), (3.0 - 2.0 ** -30, INF, 2, 3.0),
+                                            (2.0 + 2.0 ** -40, 2.5, -1, 0.0), (1.0 + 2.0 ** -30, 2.0, 1, 2.0)):
+        prim, t, p, nrm, ff = hit_rays(sc, ro, rd, t_min, t_max)
+        assert (prim == want_prim).all(), (t_min, t_max, prim[:4])
+        if want_prim >= 0:
+            assert (t == want_t).all(), (t_min, t[:4])
