@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the short runs of the other workloads (the `also` dict)")
     ap.add_argument("--no-shares", action="store_true", help="skip the per-rank share timings (also.shares)")
+    ap.add_argument("--shading-sort", type=int, default=-1, help="rt_set_shading_sort mode (diagnostics only; default: the library's)")
     args = ap.parse_args()
 
     import torch
@@ -261,6 +262,8 @@ def main():
     fpr = flops_per_ray(flat)
 
     ctx = api.Context(local_rank)
+    if args.shading_sort >= 0:
+        ctx.set_shading_sort(args.shading_sort)
     ctx.upload_scene(scene)
     # the library's kernels go on torch's current stream: ordered after the previous step's collective and
     # any fill of the accumulator, and the collective of this step is ordered after the kernel

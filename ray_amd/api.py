@@ -143,6 +143,10 @@ class Context:
         """rt_set_tail_limit: upper limit of the colour buffer for the end of a frame (0 = none); same bits either way."""
         self._check(self.lib.rt_set_tail_limit(megabytes))
 
+    def set_shading_sort(self, mode: int = 0):
+        """rt_set_shading_sort: 1 = block-sorted shading where its kernel exists (an experiment, measured slower; 0 = default); same bits."""
+        self._check(self.lib.rt_set_shading_sort(mode))
+
     # ---- scene / camera --------------------------------------------------------------------------
     def upload_scene(self, scene, set_camera: bool = True):
         sa = scene if isinstance(scene, SceneArrays) else SceneArrays(scene.flatten())

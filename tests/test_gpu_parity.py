@@ -896,7 +896,7 @@ def test_constant_medium_through_the_c_abi(rt):
                                      scenes.Shape("medium_box", (-2.0, -1.0, -3.0, 0.0, 1.5, 1.0, 2.0), 0),
                                      scenes.Shape("medium_box", (-1.0, -0.5, -1.0, 3.0, 0.5, 0.0, 0.05), 0)], None, scenes.rayview_camera())
     for sc in (scenes.smoke_scene(), only):
-        rt.upload_scene(sc, set_camera=False)
+        rt.upload_scene(sc)
         n = 30000
         lo, hi = (-1.0, 7.0) if sc.name == "smoke" else (-4.0, 4.0)
         ro = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
@@ -1116,6 +1116,47 @@ def test_sample_slices_give_the_same_frame(rt):
         rt.set_sample_slices(8, 16)
         rt.set_tail_limit(2048)
     assert ra == rb and O.same_bits_or_nan(a, b)
+
+
+def test_block_sorted_shading_gives_the_same_frame(rt):
+    """rt_set_shading_sort(1): the bounces of a block's rays shaded in order of material by whichever thread holds the
+    slot, weights pushed on the owner's path stack. Same accumulators and ray counts as the oracle / the default kernel: the built-in
+    scene at depth 10 (levels beyond the LDS part of the stack), a ragged frame with fewer tiles than waves (blocks with idle waves),
+    sample slices without a colour buffer, bands, the normal view, a random scene with a filter group (the barriers that keep scans and
+    slots apart), the Cornell-style box scene (many rects: the mode is ignored)."""
+    from ray_amd import api
+    try:
+        sc = scenes.builtin_scene()
+        rt.upload_scene(sc)
+        W, H, spp, depth = 100, 45, 20, 10
+        oacc, orays = O.render(sc, W, H, spp, depth, rng_mode=1, seed64=5, math_mode=1, n_threads=8)
+        rt.set_shading_sort(1)
+        acc, rays = rt.render(W, H, spp, depth, seed=5)
+        assert rays == orays and O.same_bits_or_nan(acc, oacc)
+        rt.set_tail_limit(0)
+        rt.set_sample_slices(2, 16)
+        acc, rays = rt.render(W, H, spp, depth, seed=5)
+        assert rt.last_kernel_ms()[1] == 1 and rays == orays and O.same_bits_or_nan(acc, oacc)
+        rt.set_tail_limit(2048)
+        rt.set_sample_slices(8, 16)
+        nacc, _ = O.render(sc, W, H, 2, depth, rng_mode=1, seed64=5, math_mode=1, n_threads=8, flags=api.RENDER_NORMALS)
+        acc, _ = rt.render(W, H, 2, depth, seed=5, flags=api.RENDER_NORMALS)
+        assert O.same_bits_or_nan(acc, nacc)
+        for name, kw, w, h, n in (("builtin", {}, 1280, 720, 16), ("random", {"half": 5}, 320, 200, 8), ("box", {}, 160, 120, 4)):
+            rt.upload_scene(scenes.get_scene(name, **kw))
+            got = {}
+            for mode in (0, 1):
+                rt.set_shading_sort(mode)
+                buf = rt.alloc(w * h * 16).zero()
+                r = rt.alloc(8).zero()
+                rt.render_into(w, h, buf, n, 8, seed=9, rays=r, band_first=1, band_stride=3)
+                got[mode] = (buf.to_numpy(np.uint32, (h, w, 4)).copy(), int(r.to_numpy(np.uint64, (1,))[0]))
+                buf.free(); r.free()
+            assert got[0][1] == got[1][1] and np.array_equal(got[0][0], got[1][0]), name
+    finally:
+        rt.set_shading_sort(0)
+        rt.set_tail_limit(2048)
+        rt.set_sample_slices(8, 16)
 
 
 def test_triangle_queue_overflow_negative_t_and_zero_t(rt):

@@ -19,6 +19,8 @@ if len(sys.argv) > 3:
 ctx = api.Context(0, lib_path=os.path.join(ROOT, "tools", os.environ.get("RT_STAMPS_LIB", "libray_amd_stamps.so")))
 scene = scenes.get_scene(wl["scene"], **wl["kw"])
 ctx.upload_scene(scene)
+if "RT_SORT" in os.environ:   # block-sorted shading: "filter" is then count + barriers + item hand-over, "shade" the shading of the items, "other" the wait for the results
+    ctx.set_shading_sort(int(os.environ["RT_SORT"]))
 W, H = wl["W"], wl["H"]
 acc = ctx.alloc(W * H * 16).zero()
 rays = ctx.alloc(8).zero()
