@@ -111,7 +111,7 @@ def cpu_baseline(scene, wl, budget_s=12.0):
 
 def executed_work(pmc, k_ms):
     """Executed (not algorithmic) VALU work of one render_kernel launch from a committed rocprofv3 PMC summary
-    (profiles/r2_pmc.json, written by tools/prof.sh for exactly this configuration). How gfx950 counts, settled with
+    (profiles/r3_pmc.json, written by tools/prof.sh for exactly this configuration). How gfx950 counts, settled with
     tools/valu_bench under --pmc (profiles/r2_valu_bench_pmc.txt): SQ_INSTS_VALU_{FMA,MUL,ADD}_F32 count one per
     wave-instruction whether packed or not, so executed FP32 flops are only bounded: [every instruction unpacked,
     every instruction packed]; SQ_ACTIVE_INST_VALU counts issue slots of 4 cycles (FP64 fma/mul/add and conversions
@@ -132,7 +132,7 @@ def executed_work(pmc, k_ms):
         "valu_insts_per_ray": None,
         "profile_kernel_ms": round(pmc["avg_ns"] * 1e-6, 3),
         "profile_vs_live_kernel_ms": round(pmc["avg_ns"] * 1e-6 / k_ms, 4) if k_ms > 0 else None,
-        "source": "profiles/r2_pmc.json (rocprofv3 --pmc passes of this configuration; packed and unpacked FP32 instructions are "
+        "source": "profiles/r3_pmc.json (rocprofv3 --pmc passes of this configuration; packed and unpacked FP32 instructions are "
                   "counted alike, hence a range)",
     }
 
@@ -155,8 +155,22 @@ def quick_run(ctx, api, scenes, torch, dev, name, frames=1):
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     n = int(rays.item())
-    return {"workload": wl["desc"], "ms_per_frame": round(1e3 * dt / frames, 3), "kernel_ms": round(k_ms / frames, 3),
-            "Mrays_per_s": round(n / dt / 1e6, 1), "rays_per_frame": n // frames}
+    out = {"workload": wl["desc"], "ms_per_frame": round(1e3 * dt / frames, 3), "kernel_ms": round(k_ms / frames, 3),
+           "Mrays_per_s": round(n / dt / 1e6, 1), "rays_per_frame": n // frames}
+    if name == "c5":
+        # the same frame the way a progressive caller renders it: 16 calls of 64 samples, each continuing the sums of the one before
+        # (RT_RENDER_CONTINUE: the same bits as the one call above, compared here)
+        ref = acc.clone()
+        per = spp // 16
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(16):
+            ctx.render_into(W, H, acc, per, depth, seed=0xC0FFEE, spp_begin=i * per, flags=api.RENDER_CONTINUE if i else 0)
+        torch.cuda.synchronize(dev)
+        dt16 = time.perf_counter() - t0
+        same = bool(torch.equal(acc.view(torch.int32), ref.view(torch.int32)))
+        out["as_16_passes_of_64spp"] = {"ms_per_frame": round(1e3 * dt16, 3), "over_one_call": round(dt16 / (dt / frames), 4), "same_bits_as_one_call": same}
+    return out
 
 
 DEFAULT_TAIL_MB, TILE_SPLIT_TAIL_MB = 2048, 20480   # rt_set_tail_limit: the library's default; what a rank of a tile-split job (owning its GPU) allows
@@ -344,16 +358,17 @@ def main():
             "roofline": {"bound": "valu_fp32", "achieved": round(achieved, 4), "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 5), "traffic": traffic,
                          "kernel": "render_kernel (kernel_ms includes tail_sum_kernel, which adds the colours of the frame's last part in "
-                                   "sample order: 0.2 % of the time, DESIGN.md 4.5b)",
+                                   "sample order: 0.1 % of the time, DESIGN.md 4.5b)",
                          "kernel_ms": round(k_ms, 3), "flops_per_ray": fpr,
-                         "traffic_note": "the accumulator is 16 B per pixel; the rest of `traffic` is the colour buffer of the frame's tail, "
-                                         "written and read once (profiles/traffic.json): < 1 % of HBM bandwidth",
+                         "traffic_note": "the accumulator is 16 B per pixel; the rest of `traffic` is the colour buffer of the frame's end "
+                                         "(bounded by rt_set_tail_limit, default 2 GiB), written and read once, and the HBM part of the path "
+                                         "stack beyond six bounces (profiles/traffic.json): < 1 % of HBM bandwidth",
                          "accounting": "algorithmic (SURVEY 8d): closest-hit scans x primitives x flops of the reference's test; "
                                        "the box hierarchy and the packed filter answer most tests without evaluating them",
                          "accumulator_GBps": round(W * H * 16 / (k_ms * 1e-3) / 1e9, 3) if k_ms > 0 else None},
         }
         try:   # executed work from the committed PMC passes, only for the exact configuration they ran
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc.json"))).get(args.workload)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc.json"))).get(args.workload)
             if pmc and world == 1 and (pmc["W"], pmc["H"], pmc["spp"]) == (W, H, spp):
                 ex = executed_work(pmc, k_ms)
                 ex["valu_insts_per_ray"] = round(pmc["counters_per_launch"]["SQ_INSTS_VALU"] * 64 / max(local_rays / max(args.steps, 1), 1), 1)
@@ -362,7 +377,7 @@ def main():
             out["roofline"]["executed"] = {"error": str(e)[:100]}
         if world == 1 and not args.no_also:
             # the other single-GPU workloads, one timed frame each, so that 1080p (BASELINE.json configs[1]) and the triangle
-            # configs are driver-observed as well; their rocprof summaries are profiles/r2_<name>_*
+            # configs are driver-observed as well; their rocprof summaries are profiles/r3_<name>_*
             out["also"] = {n: quick_run(ctx, api, scenes, torch, dev, n) for n in ("c2", "box", "c4", "c5") if n != args.workload}
             if not args.no_shares:
                 out["also"]["shares"] = shares_run(ctx, scenes, torch, dev)

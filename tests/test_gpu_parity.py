@@ -100,8 +100,8 @@ def test_shape_fixture_rays_through_gpu(rt):
         prim, t, p, nrm, ff = rt.hit_rays(g["sph_ray_o"][i:i + 1], g["sph_ray_d"][i:i + 1], 0.001, np.inf)
         assert (prim[0] >= 0) == bool(g["sph_has"][i])
         if prim[0] >= 0:
-            assert O.same_values(t[0], g["sph_t"][i]) and O.same_values(p[0], g["sph_p"][i])
-            assert O.same_values(nrm[0], g["sph_n"][i]) and ff[0] == g["sph_ff"][i]
+            assert O.same_bits_or_nan(t[0], g["sph_t"][i]) and O.same_bits_or_nan(p[0], g["sph_p"][i])
+            assert O.same_bits_or_nan(nrm[0], g["sph_n"][i]) and ff[0] == g["sph_ff"][i]
     sel = np.where(np.isinf(g["rect_tmax"]))[0]
     kinds = ["xy_rect", "xz_rect", "yz_rect"]
     seen_special = 0
@@ -113,8 +113,8 @@ def test_shape_fixture_rays_through_gpu(rt):
         assert (prim[0] >= 0) == bool(g["rect_has"][i]), i
         if prim[0] >= 0:
             seen_special += not np.isfinite(g["rect_t"][i])
-            assert O.same_values(t[0], g["rect_t"][i]) and O.same_values(p[0], g["rect_p"][i])
-            assert O.same_values(nrm[0], g["rect_n"][i]) and ff[0] == g["rect_ff"][i]
+            assert O.same_bits_or_nan(t[0], g["rect_t"][i]) and O.same_bits_or_nan(p[0], g["rect_p"][i])
+            assert O.same_bits_or_nan(nrm[0], g["rect_n"][i]) and ff[0] == g["rect_ff"][i]
 
 
 # ---- calc::ray_color: per-pixel radiance sums, bit-exact vs the oracle on the same RNG streams ---------
@@ -163,7 +163,7 @@ def test_fast_scan_equals_list_order_scan_at_scale(rt, name, kw, W, H, spp, dept
     acc_v, rays_v = rt.render(W, H, spp, depth, seed=0xBEEF, flags=4)
     assert rt.verify_mismatches() == 0
     assert rays == rays_v and rays > W * H * spp
-    assert O.same_values(acc, acc_v)
+    assert O.same_bits_or_nan(acc, acc_v)
 
 
 def test_render_edge_cases(rt):
@@ -178,11 +178,11 @@ def test_render_edge_cases(rt):
     for W, H in [(1, 1), (17, 5), (250, 3)]:
         acc, rays = rt.render(W, H, 2, 8, seed=5)
         oacc, orays = O.render(sc, W, H, 2, 8, rng_mode=1, seed64=5, math_mode=1)
-        assert rays == orays and O.same_values(acc, oacc)
+        assert rays == orays and O.same_bits_or_nan(acc, oacc)
     # normal-visualisation mode (calc.cpp:105-109)
     acc, _ = rt.render(64, 36, 2, 8, seed=5, flags=2)
     oacc, _ = O.render(sc, 64, 36, 2, 8, rng_mode=1, seed64=5, math_mode=1, flags=2)
-    assert O.same_values(acc, oacc)
+    assert O.same_bits_or_nan(acc, oacc)
     # empty world: every ray returns the background
     empty = scenes.Scene(sc.mats, [], sc.light, sc.camera)
     rt.upload_scene(empty)
@@ -210,7 +210,7 @@ def test_sample_and_row_splits_compose(rt):
     acc.zero()
     rt.render_into(W, H, acc, 6, 8, seed=9, y_begin=0, y_count=23)
     rt.render_into(W, H, acc, 6, 8, seed=9, y_begin=23, y_count=17)
-    assert O.same_values(acc.to_numpy(np.float32, (H, W, 4)), full)
+    assert O.same_bits_or_nan(acc.to_numpy(np.float32, (H, W, 4)), full)
     # interleaved 8-row bands (rt_render_bands): the shares of 3 "ranks" are disjoint and tile the frame;
     # a ragged height (last band of 3 rows), more ranks than bands, and the black (depth 0) path
     for Hb, world in [(H, 3), (43, 2), (43, 8)]:
@@ -225,7 +225,7 @@ def test_sample_and_row_splits_compose(rt):
             assert (part[~rows] == 0).all() and (part[rows][..., 3] == 5).all()
             total += part
             n += nr
-        assert n == rays_b and O.same_values(total, fullb)
+        assert n == rays_b and O.same_bits_or_nan(total, fullb)
     part, nr = rt.render(W, H, 4, 0, seed=9, band_first=1, band_stride=2)
     assert nr == 0 and (part[8:16, :, 3] == 4).all() and (part[0:8] == 0).all() and (part[..., :3] == 0).all()
 
@@ -239,7 +239,7 @@ def test_render_pixels_equals_the_frame_at_those_pixels(rt):
     W, H, spp, depth = 96, 54, 3, 8
     full, _ = rt.render(W, H, spp, depth, seed=21)
     ofull, _ = O.render(sc, W, H, spp, depth, rng_mode=1, seed64=21, math_mode=1)
-    assert O.same_values(full, ofull)
+    assert O.same_bits_or_nan(full, ofull)
     rng = np.random.default_rng(5)
     px = rng.integers(0, W * H, 1000 + 37).astype(np.int32)     # with duplicates
     acc = rt.alloc(W * H * 16).zero()
@@ -247,7 +247,7 @@ def test_render_pixels_equals_the_frame_at_those_pixels(rt):
     rt.render_pixels(W, H, acc, px, spp, depth, seed=21, rays=rays)
     got = acc.to_numpy(np.float32, (H, W, 4)).reshape(-1, 4)
     mask = np.zeros(W * H, bool); mask[px] = True
-    assert O.same_values(got[mask], full.reshape(-1, 4)[mask])
+    assert O.same_bits_or_nan(got[mask], full.reshape(-1, 4)[mask])
     assert (got[~mask] == 0).all()
     assert int(rays.to_numpy(np.uint64, (1,))[0]) > 0
     # a second pass over other samples, accumulated: equals the 2-pass frame at those pixels
@@ -256,7 +256,7 @@ def test_render_pixels_equals_the_frame_at_those_pixels(rt):
     rt.render_into(W, H, two, spp, depth, seed=21)
     rt.render_into(W, H, two, 2, depth, seed=21, spp_begin=spp, flags=1)
     got = acc.to_numpy(np.float32, (H, W, 4)).reshape(-1, 4)
-    assert O.same_values(got[mask], two.to_numpy(np.float32, (H, W, 4)).reshape(-1, 4)[mask])
+    assert O.same_bits_or_nan(got[mask], two.to_numpy(np.float32, (H, W, 4)).reshape(-1, 4)[mask])
     # depth 0: black samples, no rays; empty list: nothing happens
     acc.zero(); rays.zero()
     rt.render_pixels(W, H, acc, px[:10], 4, 0, seed=21, rays=rays)
@@ -301,7 +301,7 @@ def test_device_arithmetic_is_ieee(rt):
     ref = O.hit_rays(sc, ro, rd, 1e-9, np.inf)
     assert np.array_equal(got[0], ref[0]) and (got[0] >= 0).mean() > 0.5
     assert O.bits_equal(got[1], ref[1])
-    assert O.same_values(got[2], ref[2]) and O.same_values(got[3], ref[3])
+    assert O.same_bits_or_nan(got[2], ref[2]) and O.same_bits_or_nan(got[3], ref[3])
 
 
 def test_cpp_dropin_host_renderAll(rt, tmp_path):
@@ -318,7 +318,7 @@ def test_cpp_dropin_host_renderAll(rt, tmp_path):
     acc = np.fromfile(out, np.float32).reshape(54, 96, 4)
     sc = scenes.builtin_scene()
     oacc, _ = O.render(sc, 96, 54, 4, 8, rng_mode=1, seed64=77, math_mode=1)
-    assert O.same_values(acc, oacc)
+    assert O.same_bits_or_nan(acc, oacc)
     assert "centre ray hits prim 0" in r.stdout
 
 
@@ -370,17 +370,17 @@ def test_full_size_frame_properties(rt, name, kw, W, H, rows):
     acc = rt.alloc(W * H * 16).zero()
     rt.render_into(W, H, acc, 1, depth, seed=0xC0FFEE, spp_begin=0)
     rt.render_into(W, H, acc, 1, depth, seed=0xC0FFEE, spp_begin=1, flags=1)
-    assert O.same_values(acc.to_numpy(np.float32, (H, W, 4)), full)        # 2 samples: (a) + (b) is the same sum
+    assert O.same_bits_or_nan(acc.to_numpy(np.float32, (H, W, 4)), full)        # 2 samples: (a) + (b) is the same sum
     acc.zero()
     rt.render_into(W, H, acc, 2, depth, seed=0xC0FFEE, y_begin=0, y_count=H // 2 + 1)
     rt.render_into(W, H, acc, 2, depth, seed=0xC0FFEE, y_begin=H // 2 + 1, y_count=H - (H // 2 + 1))
-    assert O.same_values(acc.to_numpy(np.float32, (H, W, 4)), full)
+    assert O.same_bits_or_nan(acc.to_numpy(np.float32, (H, W, 4)), full)
     acc.free()
     # a few rows of the frame against the oracle (bit-exact radiance sums and ray counts at full-size pixel coordinates)
     for y in rows:
         orow = np.zeros((H, W, 4), np.float32)
         O.render(sc, W, H, 2, depth, rng_mode=1, seed64=0xC0FFEE, math_mode=1, y_begin=y, y_count=1, accum=orow)
-        assert O.same_values(full[y], orow[y])
+        assert O.same_bits_or_nan(full[y], orow[y])
 
 
 def test_gpu_image_converges_to_the_reference_image(rt):
@@ -495,7 +495,7 @@ def test_batch_boxes_edge_cases(rt):
         assert np.array_equal(got[0], ref[0]), (t_min, t_max, np.flatnonzero(got[0] != ref[0])[:10])
         assert O.bits_equal(got[1], ref[1])
         for a, b in zip(got[2:], ref[2:]):
-            assert O.same_values(a, b)
+            assert O.same_bits_or_nan(a, b)
         hits += int((got[0] > 0).sum())
     assert hits > n                                         # plenty of hits on the small spheres, not only the ground
     # duplicates: some winning index must be one of the appended copies (ties go to the later entry)
@@ -618,7 +618,7 @@ def test_rect_flag_pass_sizes_and_edge_rays(rt, n_rect):
         ref = O.hit_rays(sc, ro, rd, t_min, t_max)
         assert np.array_equal(got[0], ref[0]), np.flatnonzero(got[0] != ref[0])[:10]
         for a, b in zip(got[1:], ref[1:]):
-            assert O.same_values(a, b)
+            assert O.same_bits_or_nan(a, b)
     assert (got[0] >= 0).mean() > 0.3
 
 
@@ -665,12 +665,12 @@ def test_render_pixels_duplicates_accumulate_and_stray_indices(rt):
             for _ in range(k):
                 v = v + f[sel]
             want[sel] = v
-        assert O.same_values(got[:W * H], want)
+        assert O.same_bits_or_nan(got[:W * H], want)
         # overwrite mode with the same list: every listed pixel holds the frame's value, strays ignored
         acc.zero()
         rt.render_pixels(W, H, acc, px, spp, depth, seed=4)
         got = acc.to_numpy(np.float32, (W * H + 16, 4))
-        assert O.same_values(got[base], f[base]) and (got[W * H:] == 0).all()
+        assert O.same_bits_or_nan(got[base], f[base]) and (got[W * H:] == 0).all()
         acc.zero()
         rt.render_pixels(W, H, acc, px, 2, 0, seed=4, flags=api.RENDER_ACCUMULATE)     # black path
         got = acc.to_numpy(np.float32, (W * H + 16, 4))
@@ -699,7 +699,7 @@ def test_nowait_launch_and_contexts(rt):
     np.testing.assert_allclose(got[..., :3], want[..., :3], rtol=2e-6, atol=1e-6)
     acc.zero()
     rt.render_into(W, H, acc, spp, depth, seed=3, flags=api.RENDER_NOWAIT)
-    assert O.same_values(acc.to_numpy(np.float32, (H, W, 4)), want)        # the copy waits for the launch
+    assert O.same_bits_or_nan(acc.to_numpy(np.float32, (H, W, 4)), want)        # the copy waits for the launch
     acc.free(); rays.free()
     assert rt.lib.rt_set_device(0) == 0
     assert rt.lib.rt_set_device(63) != 0 and b"no context" in rt.lib.rt_last_error()
@@ -735,8 +735,8 @@ def test_kernels_are_ordered_with_torch_work_on_a_handed_in_stream(rt):
                     for b in range(first, (H + 7) // 8, 2):
                         mine[8 * b:8 * b + 8] = True
                     assert (got[~mine] == 0).all()
-                    assert O.same_values(got[mine], want[mine])
-                    assert O.same_values(doubled.cpu().numpy()[mine], 2.0 * want[mine])
+                    assert O.same_bits_or_nan(got[mine], want[mine])
+                    assert O.same_bits_or_nan(doubled.cpu().numpy()[mine], 2.0 * want[mine])
                     del big, doubled
     finally:
         rt.set_stream(None)
@@ -744,7 +744,7 @@ def test_kernels_are_ordered_with_torch_work_on_a_handed_in_stream(rt):
     acc.fill_(float("nan")); acc.zero_()
     torch.cuda.synchronize(dev)
     rt.render_into(W, H, acc, 1, depth, seed=0xC0FFEE, band_first=1, band_stride=2)
-    assert O.same_values(acc.cpu().numpy()[8:16], want[8:16]) and (acc.cpu().numpy()[0:8] == 0).all()
+    assert O.same_bits_or_nan(acc.cpu().numpy()[8:16], want[8:16]) and (acc.cpu().numpy()[0:8] == 0).all()
 
 
 def test_two_rank_job_drives_the_hip_library():
@@ -812,15 +812,15 @@ def test_reference_signature_caller_renderOneRay(rt, tmp_path):
     moved = scenes.builtin_scene(sphere_y=0.8)
     for k in range(n):
         want = O.trace_rays(sc if k < n // 2 else moved, ro[k:k + 1], rd[k:k + 1], depth, seed=k)
-        assert O.same_values(s["c"][k], want[0]), k
+        assert O.same_bits_or_nan(s["c"][k], want[0]), k
     # pixel sums in sample order, and calc::rgbPerSamples of them
     acc = np.zeros((2 * ticks, 3), np.float32)
     for j in range(spp):
         acc = acc + t["s"]["c"][:, j]
-    assert O.same_values(t["sum"], acc)
+    assert O.same_bits_or_nan(t["sum"], acc)
     tone = np.empty((2 * ticks, 3), np.float32)
     O.lib().orc_tonemap(2 * ticks, O.P(np.ascontiguousarray(t["sum"]), C.c_float), O.P(np.full(2 * ticks, spp, np.int32), C.c_int32), O.P(tone, C.c_float))
-    assert O.same_values(t["px"], tone)
+    assert O.same_bits_or_nan(t["px"], tone)
 
 
 def test_shape_hit_on_the_device_fills_u_v_like_the_reference(tmp_path):
@@ -877,7 +877,7 @@ def test_cpp_multi_device_host(split, shares, tmp_path):
     oacc, orays = O.render(scenes.builtin_scene(), W, H, spp, depth, rng_mode=1, seed64=seed, math_mode=1, n_threads=8)
     assert f"{orays} rays" in r.stdout and (acc[..., 3] == spp).all()
     if split == "tile" or shares == 1:
-        assert O.same_values(acc, oacc)
+        assert O.same_bits_or_nan(acc, oacc)
     else:
         np.testing.assert_allclose(acc[..., :3], oacc[..., :3], rtol=2e-6, atol=1e-6)
 
@@ -910,7 +910,7 @@ def test_constant_medium_through_the_c_abi(rt):
             assert np.array_equal(got[0], ref[0])
             assert O.bits_equal(got[1], ref[1])
             for a, b in zip(got[2:], ref[2:]):
-                assert O.same_values(a, b)
+                assert O.same_bits_or_nan(a, b)
             kinds = sc.flatten()["prim_kind"]
             med = (got[0] >= 0) & np.isin(kinds[np.maximum(got[0], 0)], (scenes.PRIM_MEDIUM_SPHERE, scenes.PRIM_MEDIUM_BOX))
             assert (got[3][med] == (1, 0, 0)).all() and (got[4][med] == 1).all()
@@ -929,7 +929,7 @@ def test_constant_medium_through_the_c_abi(rt):
     rt.upload_scene(surf)
     a, r = rt.render(64, 36, 4, 8, seed=3)
     oa, orr = O.render(surf, 64, 36, 4, 8, rng_mode=1, seed64=3, math_mode=1)
-    assert r == orr and O.same_values(a, oa)
+    assert r == orr and O.same_bits_or_nan(a, oa)
 
 
 def test_triangle_bvh_forced_on_small_and_odd_scenes(rt):
@@ -976,7 +976,7 @@ def test_triangle_bvh_forced_on_small_and_odd_scenes(rt):
                     assert np.array_equal(got[0], ref[0]), (bvh_min, n_tri)
                     assert O.bits_equal(got[1], ref[1])
                     for a, b in zip(got[2:], ref[2:]):
-                        assert O.same_values(a, b)
+                        assert O.same_bits_or_nan(a, b)
         sc = scenes.get_scene("tris", n=71)
         frames = {}
         for bvh_min in ("1", "1000000000"):
@@ -984,7 +984,7 @@ def test_triangle_bvh_forced_on_small_and_odd_scenes(rt):
             rt.upload_scene(sc)
             frames[bvh_min], rays = rt.render(480, 270, 2, 8, seed=0xBEEF, flags=4)
             assert rt.verify_mismatches() == 0 and rays > 480 * 270 * 2
-        assert O.same_values(frames["1"], frames["1000000000"])
+        assert O.same_bits_or_nan(frames["1"], frames["1000000000"])
         big = scenes.get_scene("tris", n=200)              # 79k triangles: two item slots per leaf
         os.environ["RT_TRI_BVH_MIN"] = "1"
         rt.upload_scene(big)
@@ -1017,7 +1017,7 @@ def test_render_pixels_long_lists_are_sorted_by_tile_first(rt, W, H):
         rays = rt.alloc(8).zero()
         rt.render_pixels(W, H, acc, dpx, spp, depth, seed=77, rays=rays)
         got = acc.to_numpy(np.float32, (W * H + 16, 4))
-        assert O.same_values(got[:W * H][counts > 0], f[counts > 0])
+        assert O.same_bits_or_nan(got[:W * H][counts > 0], f[counts > 0])
         assert (got[:W * H][counts == 0] == 0).all() and (got[W * H:] == 0).all()
         assert np.array_equal(dpx.to_numpy(np.int32, (n,)), px)
         acc.zero()
@@ -1027,7 +1027,7 @@ def test_render_pixels_long_lists_are_sorted_by_tile_first(rt, W, H):
         for k in range(1, int(counts.max()) + 1):
             sel = counts >= k
             want[sel] = want[sel] + f[sel]
-        assert O.same_values(got[:W * H], want) and (got[W * H:] == 0).all()
+        assert O.same_bits_or_nan(got[:W * H], want) and (got[W * H:] == 0).all()
         acc.free(); dpx.free(); rays.free()
 
 

@@ -27,18 +27,18 @@ for w in ("c3", "c2", "box", "c4", "c5"):
                   command=f"tools/prof.sh {tag}_{w}" + ("" if w == "c3" else f" --workload {w}") + " --steps 3 --warmup 1 (rocprofv3 --kernel-trace --stats, then four --pmc passes, each its own run)")
         pmc_all[w] = js
     c = js["counters_per_launch"]
-    if w == "c3" and "FETCH_SIZE" in c:
+    if "FETCH_SIZE" in c:
+        alg = wl["W"] * wl["H"] * 16
+        hbm = int(round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024))
         traffic[w] = {"W": wl["W"], "H": wl["H"], "spp": wl["spp"], "n_gpus": 1,
                       "fetch_size_kb_per_launch": round(c["FETCH_SIZE"]), "write_size_kb_per_launch": round(c["WRITE_SIZE"]),
-                      "hbm_bytes_per_launch": int(round((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)),
-                      "algorithmic_bytes_per_launch": wl["W"] * wl["H"] * 16,
-                      "tail_buffer_bytes": 16384 * wl["spp"] * 64 * 16,
+                      "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "hbm_over_algorithmic": round(hbm / alg, 1),
                       "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/prof.sh), render_kernel + tail_sum_kernel, summed over "
-                              "the launches / their number; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; source profiles/%s_c3_summary.txt. "
-                              "Algorithmic = the float4 accumulator (132.7 MB). The rest is the colour buffer of the frame's tail (DESIGN.md 4.5b): 16384 tiles x 256 "
-                              "samples x 64 pixels x 16 B = 4.29 GB, written once by render_kernel in scattered 16-byte stores (7.2 GB of write traffic: partial "
-                              "lines) and read once by tail_sum_kernel; 12.2 GB per 0.40 s frame = 30 GB/s, 0.4 %% of HBM bandwidth, bought for 3 %% of "
-                              "frame time. With RT_TAIL_MAX_MB=0 the frame moves 158 MB (profiles/r2b_traffic.json)" % rnd}
+                              "the launches / their number; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; source profiles/%s_%s_summary.txt. "
+                              "Algorithmic = the float4 accumulator. The rest is the colour buffer of the frame's end (DESIGN.md 4.5b / 4.5d, bounded by "
+                              "rt_set_tail_limit, default 2 GiB), written once by render_kernel in scattered 16-byte stores (partial lines: more write "
+                              "traffic than bytes) and read once by tail_sum_kernel, plus, where a frame is rendered in sample slices, one read and one "
+                              "write-through store of the accumulator per slice" % (rnd, w)}
 json.dump(pmc_all, open(os.path.join(ROOT, "profiles", f"{rnd}_pmc.json"), "w"), indent=1)
 if traffic:
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
