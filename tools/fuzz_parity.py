@@ -77,6 +77,12 @@ for i in range(n_cases):
     name, sc = case(i)
     W, H = int(rng.integers(8, 97)), int(rng.integers(5, 61))
     spp, depth = int(rng.integers(1, 5)), int(rng.choice([1, 2, 5, 8, 12, 20]))
+    how = ""
+    if os.environ.get("RT_FUZZ_UNITS") == "1":   # round 3: how the frame's work is cut up -- colour buffer of the frame's end, sample slices, shading sort
+        spp = int(rng.choice([1, 3, 8, 16, 17, 24, 40]))
+        mb, smin, smax, sort = int(rng.choice([0, 1, 2048])), int(rng.choice([0, 1, 3, 8])), int(rng.choice([2, 5, 16])), int(rng.integers(0, 2))
+        ctx.set_tail_limit(mb); ctx.set_sample_slices(smin, smax); ctx.set_shading_sort(sort)
+        how = f" tail {mb} MiB slices ({smin}, {smax}) sort {sort}"
     seed = int(rng.integers(0, 2 ** 62))
     ctx.upload_scene(sc)
     acc, rays = ctx.render(W, H, spp, depth, seed=seed)
@@ -114,7 +120,7 @@ for i in range(n_cases):
         bad += 1
         diff = int((acc.view(np.uint32) != oacc.view(np.uint32)).sum())
         print("   failing:", what or "render")
-    print(f"case {i:3d} {name:8s} prims {sc.flatten()['n_prims']:5d} {W}x{H} spp {spp} depth {depth:2d} rays {rays:8d} {'ok' if ok else 'MISMATCH (%d words, rays %d vs %d)' % (diff, rays, orays)}", flush=True)
+    print(f"case {i:3d} {name:8s} prims {sc.flatten()['n_prims']:5d} {W}x{H} spp {spp} depth {depth:2d}{how} rays {rays:8d} {'ok' if ok else 'MISMATCH (%d words, rays %d vs %d)' % (diff, rays, orays)}", flush=True)
 print(f"{n_cases} cases, {total_rays} rays, {bad} mismatching frames, {time.time() - t0:.0f} s")
 ctx.close()
 sys.exit(1 if bad else 0)
