@@ -1118,6 +1118,44 @@ def test_sample_slices_give_the_same_frame(rt):
     assert ra == rb and O.same_bits_or_nan(a, b)
 
 
+def test_page_locked_host_memory_in_place_of_device_buffers(rt):
+    """rt_malloc_host: rays read from, and colours / hit records written to, page-locked host memory by the kernels themselves (what
+    the reference-signature calc::ray_color / hitFromList of the mirror headers use for their one ray): the same bits as through
+    device buffers and copies."""
+    import ctypes as C
+    sc = scenes.builtin_scene()
+    rt.upload_scene(sc)
+    n = 777
+    rng = np.random.default_rng(3)
+    ro = rng.uniform(-3, 3, (n, 3)).astype(np.float32); ro[:, 2] += 1.0
+    rd = rng.standard_normal((n, 3)).astype(np.float32)
+    want = rt.trace_rays(ro, rd, 10, seed=42)
+    whit = rt.hit_rays(ro, rd, 0.001, np.inf)
+    p = C.c_void_p()
+    nbytes = n * (24 + 12 + 4 + 8 + 12 + 12 + 1) + 64
+    assert rt.lib.rt_malloc_host(C.byref(p), nbytes) == 0, rt.lib.rt_last_error()
+    try:
+        base = p.value
+        host = (C.c_char * nbytes).from_address(base)
+        view = np.frombuffer(host, np.uint8)
+        off = {"o": 0, "d": 12 * n, "rgb": 24 * n, "t": 36 * n + (-(36 * n) % 8)}
+        off["prim"] = off["t"] + 8 * n; off["p"] = off["prim"] + 4 * n; off["nrm"] = off["p"] + 12 * n; off["ff"] = off["nrm"] + 12 * n
+        view[off["o"]:off["o"] + 12 * n] = ro.view(np.uint8).reshape(-1)
+        view[off["d"]:off["d"] + 12 * n] = rd.view(np.uint8).reshape(-1)
+        assert rt.lib.rt_trace_rays(n, base + off["o"], base + off["d"], 10, 42, 0, base + off["rgb"]) == 0, rt.lib.rt_last_error()
+        got = view[off["rgb"]:off["rgb"] + 12 * n].view(np.float32).reshape(n, 3)
+        assert O.same_bits_or_nan(got, want)
+        assert rt.lib.rt_hit_rays(n, base + off["o"], base + off["d"], 0.001, float("inf"), base + off["prim"], base + off["t"], base + off["p"],
+                                  base + off["nrm"], base + off["ff"]) == 0, rt.lib.rt_last_error()
+        assert np.array_equal(view[off["prim"]:off["prim"] + 4 * n].view(np.int32), whit[0])
+        assert O.bits_equal(view[off["t"]:off["t"] + 8 * n].view(np.float64), whit[1])
+        assert O.same_bits_or_nan(view[off["p"]:off["p"] + 12 * n].view(np.float32).reshape(n, 3), whit[2])
+        assert O.same_bits_or_nan(view[off["nrm"]:off["nrm"] + 12 * n].view(np.float32).reshape(n, 3), whit[3])
+        assert np.array_equal(view[off["ff"]:off["ff"] + n], whit[4].view(np.uint8).reshape(-1))
+    finally:
+        assert rt.lib.rt_free_host(p) == 0
+
+
 def test_block_sorted_shading_gives_the_same_frame(rt):
     """rt_set_shading_sort(1): the bounces of a block's rays shaded in order of material by whichever thread holds the
     slot, weights pushed on the owner's path stack. Same accumulators and ray counts as the oracle / the default kernel: the built-in
