@@ -594,12 +594,13 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
     if (ok) {
         HitState hs;
         hit_state_init(hs, t_max);
+        bool sph_redo = false;
         {
             const FilterGroup sg_here = KARG ? load_kernarg<FilterGroup>(offsetof(DevScene, sg)) : sc.sg;
-            scan_spheres(sg_here, sc.sph_prim, r.o, r.d, r.dl2, t_min, t_max, hs, words RT_STAMP_ARG);
+            scan_spheres(sg_here, sc.sph_prim, r.o, r.d, r.dl2, t_min, t_max, hs, words, sph_redo RT_STAMP_ARG);
         }
         h.t = hs.bt; h.prim = hs.idx;
-        bool saw_nan = false;
+        bool saw_nan = sph_redo;
         if (sc.n_rect > 0) {
         const DevScene scr = KARG ? load_kernarg<DevScene>(0) : sc;   // the rects' arrays, read only by scenes that have rects
         if (RECTS == 1 || (RECTS == 2 && scr.n_rect >= kRectFlagMin)) {

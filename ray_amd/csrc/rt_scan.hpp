@@ -591,8 +591,10 @@ __device__ __forceinline__ void walk_flagged_items(uint32_t summary, int w0, con
 // Spheres of one ray (o, d, a = d.lengthSquared() as Ray.h:8 caches it). `words` is this thread's
 // column of the block's flag-word array in LDS (stride kScanBlock). sph_prim: flattened primitive
 // index per sphere slot (-1 for pads). Requires ray_in_fast_range and a finite scene. On return h is exact.
+// redo: set when the shared walk (RT_SPHERES_SHARED_WALK) cannot order two candidates; the caller then takes the list-order scan.
 __device__ __forceinline__ void scan_spheres(const FilterGroup& sg, const int* __restrict__ sph_prim, V3 o, V3 d, float a, double t_min,
-                                             double t_max, HitState& h, uint32_t* words RT_STAMP_PARAM) {
+                                             double t_max, HitState& h, uint32_t* words, bool& redo RT_STAMP_PARAM) {
+    (void)redo;
     if (sg.n_epairs == 0 && sg.n_fpairs == 0) return;
     const float tmin_lo = __double2float_rd(t_min), tmin_hi = __double2float_ru(t_min);
     const float ia = __builtin_amdgcn_rcpf(a);
@@ -664,6 +666,156 @@ __device__ __forceinline__ void scan_spheres(const FilterGroup& sg, const int* _
         const uint32_t summary = filter_words(sg, fr, h.bhi, fw0, nw, words RT_STAMP_ARG);
         RT_STAMP(2);
         walk_flagged(summary, sg.n_ewords + fw0, words, visit RT_STAMP_ARG);
+        RT_STAMP(3);
+    }
+#elif defined(RT_SPHERES_SHARED_WALK)
+    // Levels 1 AND 2 shared out among the lanes. Level 1 as below, except that the lane that filtered a batch for
+    // its owner pushes the flagged PAIRS to a second queue under the owner's name instead of writing flag words; when that queue
+    // is worked off every lane takes one entry, whoever owns it: the owner's ray through ds_bpermute (o, d, a: 7 dwords), the pair's b, c, D
+    // with the reference's operations (shapes.h:83-86), and for each sphere with D >= 0 the root the reference would accept against
+    // t_min alone (near root first, shapes.h:90-97), in FP64 -- every candidate, not only the surviving one as the per-lane walk
+    // does. The smallest root of an owner's candidates is kept in the owner's cell A (ds_min_u64 on the double's bits, mapped to an
+    // ordered integer), its primitive in cell I, written by the one lane whose root IS the cell's value after all of the round's
+    // minima are in (LDS operations of a wave complete in order). min is order-independent, and the reference's sequential rule --
+    // a sphere replaces the best so far when its accepted root is smaller, or equal with a larger index -- picks exactly the
+    // smallest accepted root (a near root beyond the best so far fails, and then so does its far root). Two candidates of one ray
+    // with the SAME root bits (duplicate spheres) cannot be ordered by cell A: the second ds_min returns its own value, and that
+    // ray takes the list-order scan (`redo`), as does a root of +-0. The owner accepts the cell against its exact-group hit.
+    constexpr int kChunk = 12, kPairRows = 11, kPairCap = kPairRows * 64, kIdxRow = 11, kCellRow = 12, kQueueRow = 14, kQueueCap = 128;
+    const int lane = int(threadIdx.x & 63);
+    uint32_t* wq = words - lane;                               // the wave's 64 columns: row k at wq + k * kScanBlock
+    unsigned long long* const cells = reinterpret_cast<unsigned long long*>(wq + kCellRow * kScanBlock);
+    auto cell_of = [&](int l) { return cells + (l >> 5) * (kScanBlock / 2) + (l & 31); };   // rows 12, 13: 32 cells each
+    constexpr unsigned long long kNoHit = ~0ull;
+    const unsigned long long here = __ballot(true);            // (the loops below are wave-uniform: the set does not change)
+    const int rank_here = __popcll(here & ((1ull << lane) - 1ull)), n_here = __popcll(here);
+    int q_len = 0, bq_len = 0;                                 // wave-uniform
+    auto walk_queue = [&]() {
+        if (q_len == 0) return;
+        *cell_of(lane) = kNoHit;
+        asm volatile("" ::: "memory");                         // (LDS operations of one wave complete in order: only the compiler must keep it)
+        for (int base = 0; base < q_len; base += n_here) {
+            RT_COUNT(0);
+            const int e = base + rank_here;
+            const bool work = e < q_len;
+            const uint32_t ent = work ? wq[(e >> 6) * kScanBlock + (e & 63)] : uint32_t(lane);
+            const int owner = int(ent & 63u), pair = int(ent >> 6);
+            const f2 oO01 = {__shfl(o.x, owner), __shfl(o.y, owner)}, oO2A = {__shfl(o.z, owner), __shfl(a, owner)};
+            const f2 oD01 = {__shfl(d.x, owner), __shfl(d.y, owner)}, oD2 = {__shfl(d.z, owner), 0.0f};
+            f2 b = {0.0f, 0.0f}, D = {-1.0f, -1.0f};
+            if (work) {
+                RT_COUNT_LANES(1);
+                const float4 A = sg.fq[2 * pair], B = sg.fq[2 * pair + 1];
+                const f2 cx = {A.x, A.y}, cy = {A.z, A.w}, cz = {B.x, B.y}, r2 = {B.z, B.w};
+                const f2 x = pk_sub_c<0>(oO01, cx), y = pk_sub_c<1>(oO01, cy), z = pk_sub_c<0>(oO2A, cz);
+                b = pk_mul_c<0>(oD01, x) + pk_mul_c<1>(oD01, y) + pk_mul_c<0>(oD2, z);   // shapes.h:83
+                const f2 c = x * x + y * y + z * z - r2;                                // shapes.h:84
+                D = b * b - pk_mul_c<1>(oO2A, c);                                       // shapes.h:86
+            }
+            uint32_t pend = (D.x >= 0.0f ? 1u : 0u) | (D.y >= 0.0f ? 2u : 0u);          // mostly 0 or one bit
+            const Recip64 ra = recip64(double(oO2A.y));
+            while (__ballot(pend != 0u) != 0ull) {                                      // one candidate per lane and trip
+                unsigned long long key = kNoHit;
+                int idx = -1;
+                if (pend != 0u) {
+                    RT_COUNT_LANES(2);
+                    const bool second = (pend & 1u) == 0u;
+                    pend &= pend - 1u;
+                    const float bb = second ? b.y : b.x, DD = second ? D.y : D.x;
+                    idx = sph_prim[2 * pair + (second ? 1 : 0)];
+                    const double sqrtd = sqrt64(double(DD)), nb = double(-bb);
+                    double root = div64(nb - sqrtd, ra);
+                    if (root < t_min) root = div64(nb + sqrtd, ra);
+                    if (root >= t_min) {
+                        const unsigned long long u = (unsigned long long)__double_as_longlong(root);
+                        key = root == 0.0 ? 0ull : ((u >> 63) ? ~u : (u | 0x8000000000000000ull));   // ordered like the doubles; +-0 cannot be told apart
+                        if (atomicMin(cell_of(owner), key) == key) atomicMin(cell_of(owner), 0ull);   // two candidates with the same root bits
+                    }
+                }
+                asm volatile("" ::: "memory");
+                if (key != kNoHit && *cell_of(owner) == key) wq[kIdxRow * kScanBlock + owner] = uint32_t(idx);
+                asm volatile("" ::: "memory");
+            }
+        }
+        const unsigned long long k = *cell_of(lane);
+        if (k == 0ull) redo = true;
+        else if (k != kNoHit) {
+            const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+            const double t = __longlong_as_double((long long)u);
+            const int idx = int(wq[kIdxRow * kScanBlock + lane]);
+            if (h.dD >= 0.0f) resolve_exact(a, t_min, t_max, h, false, 0.0f, 0.0f, -1);
+            if (!reject_t(t, t_min, h.bt, idx, h.idx)) {
+                h.bt = t; h.idx = idx;
+                h.blo = __double2float_rd(t); h.bhi = __double2float_ru(t);
+            }
+        }
+        q_len = 0;
+    };
+    auto filter_batches = [&](int fw0) {
+        for (int base = 0; base < bq_len; base += n_here) {
+            const int e = base + rank_here;
+            const bool work = e < bq_len;
+            const uint32_t ent = work ? wq[(kQueueRow + (e >> 6)) * kScanBlock + (e & 63)] : uint32_t(lane);
+            const int owner = int(ent & 63u), lb = int(ent >> 6);          // lb: batch of the chunk, 4 per word
+            const f2 D01 = {__shfl(fr.D01.x, owner), __shfl(fr.D01.y, owner)}, D2O = {__shfl(fr.D2O.x, owner), __shfl(fr.D2O.y, owner)};
+            const f2 NAM = {__shfl(fr.NAM.x, owner), __shfl(fr.NAM.y, owner)}, W01 = {__shfl(fr.W01.x, owner), __shfl(fr.W01.y, owner)};
+            const f2 W2 = {__shfl(fr.W2.x, owner), 0.0f};
+            uint32_t m = 0u;                                   // bit set: pair jj (bit 7 - jj) NOT flagged
+            if (work) {
+                const float4* __restrict__ bd = reinterpret_cast<const float4*>(sg.fi) + size_t(fw0 * 4 + lb) * 16;
+#pragma unroll RT_SHARE_UNROLL
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float4 A = bd[2 * jj], B = bd[2 * jj + 1];
+                    const f2 X = {A.x, A.y}, Y = {A.z, A.w}, Z = {B.x, B.y}, K = {B.z, B.w};
+                    f2 bq = pk_fma_cc_v<0, 1>(D01, X, D2O);
+                    bq = pk_fma_cv_v<1>(D01, Y, bq);
+                    bq = pk_fma_cv_v<0>(D2O, Z, bq);
+                    f2 Q = pk_fma_cc_v<0, 1>(NAM, K, NAM);
+                    Q = pk_fma_cv_v<0>(W01, X, Q);
+                    Q = pk_fma_cv_v<1>(W01, Y, Q);
+                    Q = pk_fma_cv_v<0>(W2, Z, Q);
+                    const f2 T = __builtin_elementwise_fma(bq, bq, Q);   // >= 0 (sign bit clear): flagged
+                    m = __builtin_amdgcn_alignbit(m, __float_as_uint(T.x) & __float_as_uint(T.y), 31);
+                }
+            }
+            uint32_t cur = work ? (~m & 0xffu) : 0u;           // bit 7 - jj: pair jj of the batch
+            const int pbase = (sg.n_ewords + fw0) * 32 + lb * 8;
+            for (;;) {
+                const unsigned long long pushing = __ballot(cur != 0u);
+                if (pushing == 0ull) break;
+                const int cnt = __popcll(pushing);
+                if (q_len + cnt > kPairCap) walk_queue();
+                if (cur != 0u) {
+                    const int pp = __builtin_clz(cur) - 24;
+                    cur &= ~(0x80u >> pp);
+                    const int slot = q_len + __popcll(pushing & ((1ull << lane) - 1ull));
+                    wq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(pbase + pp) << 6) | uint32_t(owner);
+                }
+                q_len += cnt;
+            }
+        }
+        bq_len = 0;
+    };
+    for (int fw0 = 0; fw0 < n_fwords; fw0 += kChunk) {
+        const int nw = n_fwords - fw0 < kChunk ? n_fwords - fw0 : kChunk;
+        filter_words_level0(sg, fr, h.bhi, fw0, nw, [&](int fw, const bool (&nd)[4], int real) {
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const bool need = nd[bb] && bb < real;
+                const unsigned long long pushing = __ballot(need);
+                if (pushing == 0ull) continue;
+                const int cnt = __popcll(pushing);
+                if (bq_len + cnt > kQueueCap) filter_batches(fw0);
+                if (need) {
+                    const int slot = bq_len + __popcll(pushing & ((1ull << lane) - 1ull));
+                    wq[(kQueueRow + (slot >> 6)) * kScanBlock + (slot & 63)] = (uint32_t((fw - fw0) * 4 + bb) << 6) | uint32_t(lane);
+                }
+                bq_len += cnt;
+            }
+        });
+        filter_batches(fw0);
+        RT_STAMP(2);
+        walk_queue();                                          // (a hit found now prunes the boxes of the chunks after it)
         RT_STAMP(3);
     }
 #else
