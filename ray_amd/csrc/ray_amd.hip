@@ -359,8 +359,10 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     const int lane = int(threadIdx.x & 63);
     uint32_t* wq = words - lane;                               // the wave's 64 columns: row k at wq + k * kScanBlock
     constexpr int kBatchRows = 2;                              // rows 0, 1: the queue of (batch, owner) entries of the shared filter
-    constexpr int kQueueRows = kMaskWords - 2, kQueueCap = (kQueueRows - kBatchRows) * 64;   // the last two rows hold the 64 cells
-    uint32_t* const iq = wq + kBatchRows * kScanBlock;         // the item queue's first row
+    constexpr int kChunkRows = 2;                              // rows 2, 3: the queue of (chunk, owner) entries of the shared level 0
+    constexpr int kQueueRows = kMaskWords - 2, kQueueCap = (kQueueRows - kBatchRows - kChunkRows) * 64;   // the last two rows hold the 64 cells
+    uint32_t* const cq = wq + kBatchRows * kScanBlock;         // the chunk queue's first row
+    uint32_t* const iq = wq + (kBatchRows + kChunkRows) * kScanBlock;   // the item queue's first row
     unsigned long long* const cells = reinterpret_cast<unsigned long long*>(wq + kQueueRows * kScanBlock);
     auto cell_of = [&](int l) { return cells + (l >> 5) * (kScanBlock / 2) + (l & 31); };
     constexpr unsigned long long kNoHit = ~0ull;
@@ -473,18 +475,70 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
         }
         bq_len = 0;
     };
-    {
-        const bool one_chunk_s = n_fwords <= kItemChunkWords;
-        unsigned long long pair_needs_s[2] = {~0ull, ~0ull};
-        for (int fw0 = 0; fw0 < n_fwords; fw0 += kItemChunkWords) {
-            const int ci = fw0 / kItemChunkWords;
-            if (!one_chunk_s && (ci & 1) == 0) {
-                cf2p cb = RT_CONST_F2(tg.cbnd) + (ci >> 1) * 6;
-                bool n0, n1;
-                box_pair(fr, __double2float_ru(h.t), cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], n0, n1);
-                pair_needs_s[0] = __ballot(n0); pair_needs_s[1] = __ballot(n1);
+    // Level 0 is shared out as well (round 3). The wave-uniform box tests run every chunk, word and batch that SOME
+    // lane needs for all 64 lanes: on the 9.8k-triangle frame 4.2 of the 10 chunks per scan where a lane needs 1.4, and that was
+    // 47 % of the frame. Now only the chunk boxes are tested wave-uniformly (one slab test per pair of chunks); every (chunk, owner)
+    // need goes to a third queue, and a lane takes one entry: the owner's slab constants through ds_bpermute (10 dwords; |inv| is
+    // recomputed), the chunk's 32 batch boxes through vector loads (768 bytes), 16 packed slab tests with the same arithmetic, and
+    // pushes the (batch, owner) entries of level 1. A group of a single chunk keeps the wave-uniform form (every lane needs it).
+    constexpr int kChunkCap = kChunkRows * 64;
+    int cq_len = 0;
+    auto level0_chunks = [&]() {
+        for (int base = 0; base < cq_len; base += n_here) {
+            const int e = base + rank_here;
+            const bool work = e < cq_len;
+            const uint32_t ent = work ? cq[(e >> 6) * kScanBlock + (e & 63)] : uint32_t(lane);
+            const int owner = int(ent & 63u), ci = int(ent >> 6);
+            FilterRay fo = fr;                                 // (t_lo depends on t_min alone: the same for every lane)
+            fo.I01 = f2{__shfl(fr.I01.x, owner), __shfl(fr.I01.y, owner)}; fo.I2 = f2{__shfl(fr.I2.x, owner), 0.0f};
+            fo.A01 = f2{__builtin_fabsf(fo.I01.x), __builtin_fabsf(fo.I01.y)}; fo.A2 = f2{__builtin_fabsf(fo.I2.x), 0.0f};
+            fo.KX = f2{__shfl(fr.KX.x, owner), __shfl(fr.KX.y, owner)};
+            fo.KY = f2{__shfl(fr.KY.x, owner), __shfl(fr.KY.y, owner)};
+            fo.KZ = f2{__shfl(fr.KZ.x, owner), __shfl(fr.KZ.y, owner)};
+            const float t_hi_o = __shfl(__double2float_ru(h.t), owner);
+            uint32_t cur = 0u;                                 // bit 4 wi + bb: the owner needs batch bb of word wi of the chunk
+            if (work) {
+                const int fwc = ci * kItemChunkWords;
+                const int nwc = n_fwords - fwc < kItemChunkWords ? n_fwords - fwc : kItemChunkWords;
+                const float4* __restrict__ bn = reinterpret_cast<const float4*>(tg.bnd) + size_t(fwc) * 6;
+#pragma unroll 2
+                for (int wi = 0; wi < nwc; ++wi) {
+                    const float4 q0 = bn[6 * wi], q1 = bn[6 * wi + 1], q2 = bn[6 * wi + 2], q3 = bn[6 * wi + 3], q4 = bn[6 * wi + 4], q5 = bn[6 * wi + 5];
+                    bool a0, a1, a2, a3;
+                    float e0, e1;
+                    box_pair_v(fo, t_hi_o, f2{q0.x, q0.y}, f2{q1.x, q1.y}, f2{q2.x, q2.y}, f2{q3.x, q3.y}, f2{q4.x, q4.y}, f2{q5.x, q5.y}, a0, a1, e0, e1);
+                    box_pair_v(fo, t_hi_o, f2{q0.z, q0.w}, f2{q1.z, q1.w}, f2{q2.z, q2.w}, f2{q3.z, q3.w}, f2{q4.z, q4.w}, f2{q5.z, q5.w}, a2, a3, e0, e1);
+                    const int real = tg.n_fbatches - (fwc + wi) * 4;
+                    const uint32_t bits = (a0 && 0 < real ? 1u : 0u) | (a1 && 1 < real ? 2u : 0u) | (a2 && 2 < real ? 4u : 0u) | (a3 && 3 < real ? 8u : 0u);
+                    cur |= bits << (4 * wi);
+                }
             }
-            if (pair_needs_s[ci & 1] == 0ull) continue;
+            for (;;) {
+                const unsigned long long pushing = __ballot(cur != 0u);
+                if (pushing == 0ull) break;
+                const int cnt = __popcll(pushing);
+                if (bq_len + cnt > kBatchCap) filter_batches();
+                if (cur != 0u) {
+                    const int p = __builtin_ctz(cur);
+                    cur &= cur - 1u;
+                    const int slot = bq_len + __popcll(pushing & ((1ull << lane) - 1ull));
+                    wq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(ci * kItemChunkWords * 4 + p) << 6) | uint32_t(owner);
+                }
+                bq_len += cnt;
+            }
+        }
+        cq_len = 0;
+    };
+    {
+        // Which way a scan goes is decided from the chunk boxes (tested wave-uniformly for 32 chunks at a time, a bit per chunk and
+        // lane): a round of the shared form costs about as much as 2.4 chunks of the wave-uniform form (16 slab tests, 768 bytes of
+        // vector loads in four dependent groups, the pushes), so it is taken when its rounds replace more chunks than that - the
+        // mixed 4K frame: 13 (chunk, lane) needs spread over 4.1 chunks per scan - and not when many lanes want the same few
+        // chunks - the 9.8k-triangle mesh alone: 88 needs over 4.2 chunks.
+        const bool one_chunk_s = n_fwords <= kItemChunkWords;
+        const int n_chunks = (n_fwords + kItemChunkWords - 1) / kItemChunkWords;
+        auto chunk_uniform = [&](int ci) {                     // level 0 of one chunk, wave-uniform
+            const int fw0 = ci * kItemChunkWords;
             const int nw = n_fwords - fw0 < kItemChunkWords ? n_fwords - fw0 : kItemChunkWords;
             filter_words_level0(tg, fr, __double2float_ru(h.t), fw0, nw, [&](int fw, const bool (&nd)[4], int real) {
 #pragma unroll
@@ -501,9 +555,52 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
                     bq_len += cnt;
                 }
             });
-            RT_STAMP(2);
-            if (bq_len >= 64) { filter_batches(); RT_STAMP(2); }
-            if (q_len >= kItemFlush) { walk_queue(); RT_STAMP(3); }
+        };
+        for (int cg = 0; cg < n_chunks; cg += 32) {
+            const int ng = n_chunks - cg < 32 ? n_chunks - cg : 32;
+            uint32_t my_chunks = one_chunk_s ? 1u : 0u;        // bit c: this lane needs chunk cg + c
+            int n_needs = one_chunk_s ? n_here : 0, n_union = one_chunk_s ? 1 : 0;   // wave-uniform
+            if (!one_chunk_s) {
+                const float t_hi = __double2float_ru(h.t);
+                for (int q = 0; 2 * q < ng; ++q) {
+                    cf2p cb = RT_CONST_F2(tg.cbnd) + ((cg >> 1) + q) * 6;
+                    bool n0, n1;
+                    box_pair(fr, t_hi, cb[0], cb[1], cb[2], cb[3], cb[4], cb[5], n0, n1);
+                    n1 = n1 && 2 * q + 1 < ng;
+                    const unsigned long long b0 = __ballot(n0), b1 = __ballot(n1);
+                    my_chunks |= (n0 ? 1u : 0u) << (2 * q) | (n1 ? 2u : 0u) << (2 * q);
+                    n_needs += __popcll(b0) + __popcll(b1);
+                    n_union += (b0 != 0ull ? 1 : 0) + (b1 != 0ull ? 1 : 0);
+                }
+            }
+            RT_STAMP(1);
+            if (n_union == 0) continue;
+            const int rounds = (n_needs + n_here - 1) / n_here;
+            const bool shared = !one_chunk_s && rounds * 12 < n_union * 5;
+#ifdef RT_STAMP_LEVEL0
+            if (shared) RT_EVENT(7);                           // (diagnostic: scans that take the shared form)
+#endif
+            for (int c = 0; c < ng; ++c) {
+                const unsigned long long needs = __ballot((my_chunks >> c) & 1u);
+                if (needs == 0ull) continue;
+                if (shared) {
+                    const int cnt = __popcll(needs);
+                    if (cq_len + cnt > kChunkCap) level0_chunks();
+                    if ((needs >> lane) & 1ull) {
+                        const int slot = cq_len + __popcll(needs & ((1ull << lane) - 1ull));
+                        cq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(cg + c) << 6) | uint32_t(lane);
+                    }
+                    cq_len += cnt;
+                    if (cq_len >= 64) level0_chunks();
+                } else {
+                    chunk_uniform(cg + c);
+                }
+                RT_STAMP(1);
+                if (bq_len >= 64) { filter_batches(); RT_STAMP(2); }
+                if (q_len >= kItemFlush) { walk_queue(); RT_STAMP(3); }
+            }
+            level0_chunks();
+            RT_STAMP(1);
         }
         filter_batches();
         RT_STAMP(2);
@@ -583,6 +680,7 @@ __device__ __forceinline__ T load_kernarg(size_t offset) {
 // 2 = decide at run time (the one-ray kernels). A compile-time choice for the render kernel for the same reason as RECTS:
 // the medium's code merely being present costs the other workloads registers (16 VGPRs spilled to scratch).
 // TRIS: 0 = the triangle group through the flat box / filter / walk levels, 1 = through the BVH (the launcher picks it
+// TRIS 3 = the launcher knows that the scene has no triangles: their scan is compiled out (fewer registers for the sphere scenes)
 // when rt_upload_scene built one), 2 = decide at run time.
 // KARG: the caller is render_kernel, whose first argument is the scene: every group's fields are read from the kernarg segment
 // where its scan starts (load_kernarg), so that they occupy scalar registers during that scan only.
@@ -638,7 +736,7 @@ __device__ __forceinline__ Hit closest_hit(const DevScene& sc, const Ray& r, dou
             scan_rects<2>(scr.rect, scr.rect_f, scr.rect_prim, scr.n_rect_xy + scr.n_rect_xz, scr.n_rect, r, t_min, tminf, h.t, h.prim, btf, saw_nan);
         }
         }
-        if (!saw_nan && (sc.tg.n_epairs | sc.tg.n_fpairs) != 0) {
+        if (TRIS != 3 && !saw_nan && (sc.tg.n_epairs | sc.tg.n_fpairs) != 0) {
             const DevScene sc_tri = KARG ? load_kernarg<DevScene>(0) : sc;
             if (TRIS == 1 || (TRIS == 2 && sc.tbvh != nullptr)) scan_triangles_bvh(sc_tri, r, t_min, h, words);
             else scan_triangles(sc_tri, r, t_min, h, words, saw_nan RT_STAMP_ARG);
@@ -1015,7 +1113,7 @@ __device__ unsigned long long g_wave_times[8192][2];
 // cheap against their shading (no filter group, few rects, no triangles, no medium); not with VERIFY or PIXELS
 template <bool VERIFY, bool PIXELS = false, int RECTS = 0, int MEDIA = 0, int TRIS = 0, bool CHAIN = true, bool SORT = false>
 __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamera cam, RenderArgs ra_entry) {
-    static_assert(!SORT || (!VERIFY && !PIXELS && MEDIA == 0 && TRIS == 0 && RECTS == 0), "block-sorted shading: plain frames only");
+    static_assert(!SORT || (!VERIFY && !PIXELS && MEDIA == 0 && TRIS == 3 && RECTS == 0), "block-sorted shading: plain frames of scenes without triangles only");
     __shared__ RT_WORDS_ALIGN uint32_t s_words[kMaskWords * kBlock];
     uint32_t* words = s_words + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -2660,8 +2758,10 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     else if (bvh) { if (chain) RT_LAUNCH(false, false, 0, 0, 1, true); else RT_LAUNCH(false, false, 0, 0, 1, false); }
     else if (verify && many_rects) RT_LAUNCH(true, false, 1, 0, 0, true);
     else if (verify) RT_LAUNCH(true, false, 0, 0, 0, true);
+    else if (many_rects && !has_tris) { if (chain) RT_LAUNCH(false, false, 1, 0, 3, true); else RT_LAUNCH(false, false, 1, 0, 3, false); }
     else if (many_rects) { if (chain) RT_LAUNCH(false, false, 1, 0, 0, true); else RT_LAUNCH(false, false, 1, 0, 0, false); }
-    else if (sort) { if (chain) RT_LAUNCH(false, false, 0, 0, 0, true, true); else RT_LAUNCH(false, false, 0, 0, 0, false, true); }
+    else if (sort) { if (chain) RT_LAUNCH(false, false, 0, 0, 3, true, true); else RT_LAUNCH(false, false, 0, 0, 3, false, true); }
+    else if (!has_tris) { if (chain) RT_LAUNCH(false, false, 0, 0, 3, true); else RT_LAUNCH(false, false, 0, 0, 3, false); }
     else { if (chain) RT_LAUNCH(false, false, 0, 0, 0, true); else RT_LAUNCH(false, false, 0, 0, 0, false); }
 #undef RT_LAUNCH
     if (n_tail > 0) hipLaunchKernelGGL(tail_sum_kernel, dim3((n_tail * 64 + 255) / 256), dim3(256), 0, G().stream, ra);

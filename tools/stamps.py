@@ -43,7 +43,7 @@ print(f"{wl['desc']} at {spp} spp, depth {wl['depth']}: {ms:.2f} ms, {n_rays / m
 scans = t[11]
 for n, v in zip(names, t[:8]):
     print(f"  {n:22s} {100.0 * v / tot:6.2f} %   {v / max(scans, 1):9.0f} cycles per wave-scan")
-print(f"  hand-outs refused with four unfinished units {batches} ({batches / max(scans, 1):.4f} per wave-scan); polls of a queue entry that was not there {other} ({other / max(scans, 1):.4f} per wave-scan)")
+print(f"  slot 1 (triangle scenes: cycles in level 0 of the filter; else hand-outs refused with four unfinished units) {batches} ({batches / max(scans, 1):.1f} per wave-scan); slot 7 (events) {other} ({other / max(scans, 1):.4f} per wave-scan)")
 print(f"  wave-scans {scans}, rays per wave-scan {n_rays / max(scans, 1):.1f} (64 = all lanes busy)")
 print(f"  walk passes per wave-scan {t[8] / max(scans, 1):.2f}; per ray: flagged sphere pairs {t[9] / max(n_rays, 1):.2f}, sphere candidates (d >= 0) {t[10] / max(n_rays, 1):.2f}")
 ctx.close()
