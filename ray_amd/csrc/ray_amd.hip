@@ -482,6 +482,10 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     // recomputed), the chunk's 32 batch boxes through vector loads (768 bytes), 16 packed slab tests with the same arithmetic, and
     // pushes the (batch, owner) entries of level 1. A group of a single chunk keeps the wave-uniform form (every lane needs it).
     constexpr int kChunkCap = kChunkRows * 64;
+#ifndef RT_L0_ROUND_COST
+#define RT_L0_ROUND_COST 10
+#endif
+    constexpr int kLevel0RoundCost = RT_L0_ROUND_COST;         // what a round of the shared level 0 costs, in fifths of a wave-uniform chunk (swept: 1.6 .. 4, best at 2)
     int cq_len = 0;
     auto level0_chunks = [&]() {
         for (int base = 0; base < cq_len; base += n_here) {
@@ -576,7 +580,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
             RT_STAMP(1);
             if (n_union == 0) continue;
             const int rounds = (n_needs + n_here - 1) / n_here;
-            const bool shared = !one_chunk_s && rounds * 12 < n_union * 5;
+            const bool shared = !one_chunk_s && rounds * kLevel0RoundCost < n_union * 5;
 #ifdef RT_STAMP_LEVEL0
             if (shared) RT_EVENT(7);                           // (diagnostic: scans that take the shared form)
 #endif
