@@ -64,6 +64,10 @@ def case(i):
     if k == 2:
         return "box", scenes.box_scene(light_on_panel=bool(rng.integers(0, 2)))
     if k == 3:
+        if os.environ.get("RT_FUZZ_MESHES") == "1":   # meshes of several filter chunks (576 .. 5000 items): the shared level 0 of the triangle filter and its decision per scan
+            if rng.integers(0, 2):
+                return "tris", scenes.tri_mesh_scene(n=int(rng.integers(24, 72)), aperture=f32(rng.choice([0.0, 0.1])))
+            return "mixed", scenes.mixed_scene(half=int(rng.integers(1, 5)), n=int(rng.integers(24, 72)), seed=int(rng.integers(1, 1000)))
         return "mixed", scenes.mixed_scene(half=int(rng.integers(1, 5)), n=int(rng.integers(3, 30)), seed=int(rng.integers(1, 1000)))
     if k == 4:
         return "smoke", scenes.smoke_scene(density=f32(rng.uniform(0.05, 2.0)))
