@@ -488,8 +488,13 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     constexpr int kLevel0RoundCost = RT_L0_ROUND_COST;         // what a round of the shared level 0 costs, in fifths of a wave-uniform chunk (swept: 1.6 .. 4, best at 2)
     int cq_len = 0;
     auto level0_chunks = [&]() {
-        for (int base = 0; base < cq_len; base += n_here) {
-            const int e = base + rank_here;
+        // few entries: 2, 4 or 8 lanes share an entry, each taking a part of the chunk's words (the mixed 4K frame queues 13 entries
+        // per scan: a round in which 51 lanes idle through 16 slab tests would cost what a full one does)
+        const int lshift = cq_len * 8 <= n_here ? 3 : (cq_len * 4 <= n_here ? 2 : (cq_len * 2 <= n_here ? 1 : 0));
+        const int per = kItemChunkWords >> lshift;             // words per lane
+        for (int base = 0; base < (cq_len << lshift); base += n_here) {
+            const int u = base + rank_here;
+            const int e = u >> lshift, part = u & ((1 << lshift) - 1);
             const bool work = e < cq_len;
             const uint32_t ent = work ? cq[(e >> 6) * kScanBlock + (e & 63)] : uint32_t(lane);
             const int owner = int(ent & 63u), ci = int(ent >> 6);
@@ -505,8 +510,9 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
                 const int fwc = ci * kItemChunkWords;
                 const int nwc = n_fwords - fwc < kItemChunkWords ? n_fwords - fwc : kItemChunkWords;
                 const float4* __restrict__ bn = reinterpret_cast<const float4*>(tg.bnd) + size_t(fwc) * 6;
+                const int w_end = (part + 1) * per < nwc ? (part + 1) * per : nwc;
 #pragma unroll 2
-                for (int wi = 0; wi < nwc; ++wi) {
+                for (int wi = part * per; wi < w_end; ++wi) {
                     const float4 q0 = bn[6 * wi], q1 = bn[6 * wi + 1], q2 = bn[6 * wi + 2], q3 = bn[6 * wi + 3], q4 = bn[6 * wi + 4], q5 = bn[6 * wi + 5];
                     bool a0, a1, a2, a3;
                     float e0, e1;
@@ -579,8 +585,10 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
             }
             RT_STAMP(1);
             if (n_union == 0) continue;
+            // (a round in which 2, 4 or 8 lanes share an entry is priced at 0.6, 0.4, 0.3 of a full one)
             const int rounds = (n_needs + n_here - 1) / n_here;
-            const bool shared = !one_chunk_s && rounds * kLevel0RoundCost < n_union * 5;
+            const int tenths = n_needs * 8 <= n_here ? 3 : (n_needs * 4 <= n_here ? 4 : (n_needs * 2 <= n_here ? 6 : 10 * rounds));
+            const bool shared = !one_chunk_s && tenths * kLevel0RoundCost < n_union * 50;
 #ifdef RT_STAMP_LEVEL0
             if (shared) RT_EVENT(7);                           // (diagnostic: scans that take the shared form)
 #endif
