@@ -487,15 +487,18 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
 #endif
     constexpr int kLevel0RoundCost = RT_L0_ROUND_COST;         // what a round of the shared level 0 costs, in fifths of a wave-uniform chunk (swept: 1.6 .. 4, best at 2)
     int cq_len = 0;
-    auto level0_chunks = [&]() {
+    // all: every entry; otherwise whole rounds only, and what is left stays in the queue for the next call (its round will be fuller,
+    // or, at the scan's end, shared by several lanes per entry)
+    auto level0_chunks = [&](bool all) {
+        const int n_take = all ? cq_len : cq_len / n_here * n_here;
         // few entries: 2, 4 or 8 lanes share an entry, each taking a part of the chunk's words (the mixed 4K frame queues 13 entries
         // per scan: a round in which 51 lanes idle through 16 slab tests would cost what a full one does)
-        const int lshift = cq_len * 8 <= n_here ? 3 : (cq_len * 4 <= n_here ? 2 : (cq_len * 2 <= n_here ? 1 : 0));
+        const int lshift = n_take * 8 <= n_here ? 3 : (n_take * 4 <= n_here ? 2 : (n_take * 2 <= n_here ? 1 : 0));
         const int per = kItemChunkWords >> lshift;             // words per lane
-        for (int base = 0; base < (cq_len << lshift); base += n_here) {
+        for (int base = 0; base < (n_take << lshift); base += n_here) {
             const int u = base + rank_here;
             const int e = u >> lshift, part = u & ((1 << lshift) - 1);
-            const bool work = e < cq_len;
+            const bool work = e < n_take;
             const uint32_t ent = work ? cq[(e >> 6) * kScanBlock + (e & 63)] : uint32_t(lane);
             const int owner = int(ent & 63u), ci = int(ent >> 6);
             FilterRay fo = fr;                                 // (t_lo depends on t_min alone: the same for every lane)
@@ -537,7 +540,16 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
                 bq_len += cnt;
             }
         }
-        cq_len = 0;
+        const int rem = cq_len - n_take;                       // < n_here <= 64 entries stay: moved to the front
+        if (rem > 0 && n_take > 0) {
+            asm volatile("" ::: "memory");
+            uint32_t ent = 0u;
+            if (rank_here < rem) ent = cq[((n_take + rank_here) >> 6) * kScanBlock + ((n_take + rank_here) & 63)];   // (by rank: lanes outside the scan are not here)
+            asm volatile("" ::: "memory");
+            if (rank_here < rem) cq[rank_here] = ent;
+            asm volatile("" ::: "memory");
+        }
+        cq_len = rem;
     };
     {
         // Which way a scan goes is decided from the chunk boxes (tested wave-uniformly for 32 chunks at a time, a bit per chunk and
@@ -597,13 +609,13 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
                 if (needs == 0ull) continue;
                 if (shared) {
                     const int cnt = __popcll(needs);
-                    if (cq_len + cnt > kChunkCap) level0_chunks();
+                    if (cq_len + cnt > kChunkCap) level0_chunks(false);
                     if ((needs >> lane) & 1ull) {
                         const int slot = cq_len + __popcll(needs & ((1ull << lane) - 1ull));
                         cq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(cg + c) << 6) | uint32_t(lane);
                     }
                     cq_len += cnt;
-                    if (cq_len >= 64) level0_chunks();
+                    if (cq_len >= 64) level0_chunks(false);
                 } else {
                     chunk_uniform(cg + c);
                 }
@@ -611,7 +623,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
                 if (bq_len >= 64) { filter_batches(); RT_STAMP(2); }
                 if (q_len >= kItemFlush) { walk_queue(); RT_STAMP(3); }
             }
-            level0_chunks();
+            level0_chunks(true);
             RT_STAMP(1);
         }
         filter_batches();

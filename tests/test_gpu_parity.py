@@ -151,6 +151,10 @@ def test_radiance_sums_bit_exact_vs_oracle(rt, name, kw, W, H, spp, depth):
     ("builtin", {}, 640, 360, 8, 10),
     ("mixed", {"half": 5, "n": 9}, 320, 180, 2, 8),
     ("tris", {"n": 71}, 480, 270, 2, 8),          # 9800 triangles: 10 chunks of the triangle group
+    # the shared level 0 of the triangle filter: the mixed scene, where a few lanes of a wave need a chunk (entries
+    # shared by several lanes, remainders kept in the queue), on a ragged frame (lanes outside the frame are not in the scan)
+    ("mixed", {"half": 11, "n": 71}, 1283, 721, 1, 8),
+    ("tris", {"n": 40}, 333, 187, 2, 8),
 ])
 def test_fast_scan_equals_list_order_scan_at_scale(rt, name, kw, W, H, spp, depth):
     """RT_RENDER_VERIFY: every closest-hit scan of the frame (millions of primary and bounce rays) is
