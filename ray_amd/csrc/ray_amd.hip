@@ -369,16 +369,30 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     int q_len = 0;                                             // wave-uniform
     const unsigned long long here = __ballot(true);            // (the loops below are wave-uniform: the set does not change)
     const int rank_here = __popcll(here & ((1ull << lane) - 1ull)), n_here = __popcll(here);
-    auto walk_queue = [&]() {
-        if (q_len == 0) return;
+    // (all = false, here and in the two queues before this one: whole rounds only, what is left stays queued for a fuller round later)
+    auto keep_rest = [&](uint32_t* q, int n_take, int& len) {
+        const int rem = len - n_take;                          // < n_here <= 64 entries: moved to the front (by rank: lanes outside the scan are not here)
+        if (rem > 0 && n_take > 0) {
+            asm volatile("" ::: "memory");
+            uint32_t ent = 0u;
+            if (rank_here < rem) ent = q[((n_take + rank_here) >> 6) * kScanBlock + ((n_take + rank_here) & 63)];
+            asm volatile("" ::: "memory");
+            if (rank_here < rem) q[rank_here] = ent;
+            asm volatile("" ::: "memory");
+        }
+        len = rem;
+    };
+    auto walk_queue = [&](bool all) {
+        const int n_take = all ? q_len : q_len / n_here * n_here;
+        if (n_take == 0) return;
         *cell_of(lane) = kNoHit;
         const float bt_f = __double2float_ru(h.t);
         const float tmin_f = __double2float_rd(t_min);
         asm volatile("" ::: "memory");                         // (LDS operations of one wave complete in order: only the compiler must keep it)
-        for (int base = 0; base < q_len; base += n_here) {    // the lanes that are in this scan share the entries out
+        for (int base = 0; base < n_take; base += n_here) {   // the lanes that are in this scan share the entries out
             RT_COUNT(0);
             const int e = base + rank_here;
-            const bool work = e < q_len;
+            const bool work = e < n_take;
             const uint32_t ent = work ? iq[(e >> 6) * kScanBlock + (e & 63)] : uint32_t(lane);
             const int owner = int(ent & 63u), item = int(ent >> 6);
             Ray rr;                                            // the owner's ray and t range (every lane of the scan takes part in the exchange)
@@ -413,7 +427,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
             const int idx = int(0xffffffffu - uint32_t(k));
             if (t >= t_min && t <= h.t && !(t == h.t && idx < h.prim)) { h.t = t; h.prim = idx; }   // tri_t's last test, against the exact range
         }
-        q_len = 0;
+        keep_rest(iq, n_take, q_len);
     };
     // Level 1 is shared out the same way. The wave-uniform filter runs every batch that SOME lane needs for all 64 lanes (18.9
     // batches per scan on the 9.8k-triangle frame where a lane needs 3). Level 0 says per lane which batches it needs: (batch,
@@ -422,10 +436,11 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     // constants through ds_bpermute, the same packed FMAs - and pushes the flagged items to the item queue under the owner's name.
     constexpr int kBatchCap = kBatchRows * 64;
     int bq_len = 0;
-    auto filter_batches = [&]() {
-        for (int base = 0; base < bq_len; base += n_here) {
+    auto filter_batches = [&](bool all) {
+        const int n_take = all ? bq_len : bq_len / n_here * n_here;
+        for (int base = 0; base < n_take; base += n_here) {
             const int e = base + rank_here;
-            const bool work = e < bq_len;
+            const bool work = e < n_take;
             const uint32_t ent = work ? wq[(e >> 6) * kScanBlock + (e & 63)] : uint32_t(lane);
             const int owner = int(ent & 63u), batch = int(ent >> 6);
             const f2 D01 = {__shfl(fr.D01.x, owner), __shfl(fr.D01.y, owner)}, D2O = {__shfl(fr.D2O.x, owner), __shfl(fr.D2O.y, owner)};
@@ -456,7 +471,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
                 const unsigned long long push0 = __ballot(cur0 != 0u), push1 = __ballot(cur1 != 0u);
                 if ((push0 | push1) == 0ull) break;
                 const int cnt0 = __popcll(push0), cnt = cnt0 + __popcll(push1);
-                if (q_len + cnt > kQueueCap) walk_queue();
+                if (q_len + cnt > kQueueCap) walk_queue(false);
                 const unsigned long long below = (1ull << lane) - 1ull;
                 if (cur0 != 0u) {
                     const int p = __builtin_clz(cur0) - 24;
@@ -473,7 +488,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
                 q_len += cnt;
             }
         }
-        bq_len = 0;
+        keep_rest(wq, n_take, bq_len);
     };
     // Level 0 is shared out as well (round 3). The wave-uniform box tests run every chunk, word and batch that SOME
     // lane needs for all 64 lanes: on the 9.8k-triangle frame 4.2 of the 10 chunks per scan where a lane needs 1.4, and that was
@@ -530,7 +545,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
                 const unsigned long long pushing = __ballot(cur != 0u);
                 if (pushing == 0ull) break;
                 const int cnt = __popcll(pushing);
-                if (bq_len + cnt > kBatchCap) filter_batches();
+                if (bq_len + cnt > kBatchCap) filter_batches(false);
                 if (cur != 0u) {
                     const int p = __builtin_ctz(cur);
                     cur &= cur - 1u;
@@ -540,16 +555,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
                 bq_len += cnt;
             }
         }
-        const int rem = cq_len - n_take;                       // < n_here <= 64 entries stay: moved to the front
-        if (rem > 0 && n_take > 0) {
-            asm volatile("" ::: "memory");
-            uint32_t ent = 0u;
-            if (rank_here < rem) ent = cq[((n_take + rank_here) >> 6) * kScanBlock + ((n_take + rank_here) & 63)];   // (by rank: lanes outside the scan are not here)
-            asm volatile("" ::: "memory");
-            if (rank_here < rem) cq[rank_here] = ent;
-            asm volatile("" ::: "memory");
-        }
-        cq_len = rem;
+        keep_rest(cq, n_take, cq_len);
     };
     {
         // Which way a scan goes is decided from the chunk boxes (tested wave-uniformly for 32 chunks at a time, a bit per chunk and
@@ -569,7 +575,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
                     const unsigned long long pushing = __ballot(need);
                     if (pushing == 0ull) continue;
                     const int cnt = __popcll(pushing);
-                    if (bq_len + cnt > kBatchCap) filter_batches();
+                    if (bq_len + cnt > kBatchCap) filter_batches(false);
                     if (need) {
                         const int slot = bq_len + __popcll(pushing & ((1ull << lane) - 1ull));
                         wq[(slot >> 6) * kScanBlock + (slot & 63)] = (uint32_t(fw * 4 + bb) << 6) | uint32_t(lane);
@@ -620,15 +626,15 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
                     chunk_uniform(cg + c);
                 }
                 RT_STAMP(1);
-                if (bq_len >= 64) { filter_batches(); RT_STAMP(2); }
-                if (q_len >= kItemFlush) { walk_queue(); RT_STAMP(3); }
+                if (bq_len >= 64) { filter_batches(false); RT_STAMP(2); }
+                if (q_len >= kItemFlush) { walk_queue(false); RT_STAMP(3); }
             }
             level0_chunks(true);
             RT_STAMP(1);
         }
-        filter_batches();
+        filter_batches(true);
         RT_STAMP(2);
-        walk_queue();
+        walk_queue(true);
         RT_STAMP(3);
     }
 #endif
