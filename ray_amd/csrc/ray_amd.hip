@@ -609,6 +609,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
             const bool shared = !one_chunk_s && tenths * kLevel0RoundCost < n_union * 50;
 #ifdef RT_STAMP_LEVEL0
             if (shared) RT_EVENT(7);                           // (diagnostic: scans that take the shared form)
+            if (rank_here == 0) { stp.cnt[1] += n_union; stp.cnt[2] += n_needs; }   // (diagnostic: chunks some lane needs, (chunk, lane) needs: per scan, on top of the per-ray counts)
 #endif
             for (int c = 0; c < ng; ++c) {
                 const unsigned long long needs = __ballot((my_chunks >> c) & 1u);
