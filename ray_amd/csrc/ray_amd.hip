@@ -389,9 +389,11 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
         const float bt_f = __double2float_ru(h.t);
         const float tmin_f = __double2float_rd(t_min);
         asm volatile("" ::: "memory");                         // (LDS operations of one wave complete in order: only the compiler must keep it)
-        for (int base = 0; base < n_take; base += n_here) {   // the lanes that are in this scan share the entries out
+        const int lshift = n_take * 2 <= n_here ? 1 : 0;       // few entries: two lanes to an item, a triangle each
+        for (int base = 0; base < (n_take << lshift); base += n_here) {   // the lanes that are in this scan share the entries out
             RT_COUNT(0);
-            const int e = base + rank_here;
+            const int u = base + rank_here;
+            const int e = u >> lshift;
             const bool work = e < n_take;
             const uint32_t ent = work ? iq[(e >> 6) * kScanBlock + (e & 63)] : uint32_t(lane);
             const int owner = int(ent & 63u), item = int(ent >> 6);
@@ -401,8 +403,8 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
             rr.dl2 = 0.0f;
             const float bt_o = __shfl(bt_f, owner), tmin_o = __shfl(tmin_f, owner);
             if (work) {
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
+                const int h0 = lshift ? (u & 1) : 0, h1 = lshift ? (u & 1) + 1 : 2;
+                for (int hh = h0; hh < h1; ++hh) {
                     const int slot = 2 * item + hh;
                     const int idx = sc.tri_prim[slot];
                     double t;
