@@ -139,8 +139,9 @@ int rt_set_tail_limit(int64_t megabytes);
 /* Block-sorted shading, an experiment kept for the record: mode 1 shades the bounces of a block's 256 rays in
  * order of material, so that a wave executes one material's code instead of all of them (plain frames of scenes without triangles,
  * constant_medium or a rect flag pass; other calls ignore the mode). Frames are bit-identical either way. Measured on MI355X
- * it is SLOWER -- the reference's built-in scene at 1080p / 64 spp: lane utilisation 37 -> 49 %, 12 % fewer instructions, but the
- * two barriers per trip leave issue slots empty, 14.0 -> 14.3 ms; the 485-sphere frame +8 % -- hence mode 0 is the default.
+ * it does not pay -- the reference's built-in scene at 1080p / 64 spp: lane utilisation 37 -> 48 %, 16 % fewer instructions, but the
+ * two barriers per trip leave issue slots empty: 14.0 ms either way (1 - 2 % slower before the kernels lost the triangle scan); the
+ * 485-sphere frame +8 % -- hence mode 0 is the default.
  * No counterpart in the reference.                                                                       */
 int rt_set_shading_sort(int mode);
 /* Destroys the calling thread's current context.                                                           */

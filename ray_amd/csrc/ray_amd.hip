@@ -2781,7 +2781,7 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     const bool bvh = G().scene.tbvh != nullptr && !many_rects;   // (a scene with many rects AND a triangle BVH takes the flat triangle path)
     const bool chain = ra.n_slices > 1;
     // block-sorted shading (render_kernel, SORT): on request only. It raises the lane utilisation of the built-in scene's
-    // frame from 37 to 49 % and executes 12 % fewer instructions, but the two barriers per trip leave issue slots empty: 14.3 against 14.0 ms
+    // frame from 37 to 48 % and executes 16 % fewer instructions, but the two barriers per trip leave issue slots empty: a tie at 14.0 ms
     const bool has_tris = (G().scene.tg.n_epairs | G().scene.tg.n_fpairs) != 0;
     const bool sort = G().sort_mode > 0 && !verify && G().scene.n_med == 0 && !has_tris && !many_rects;
     ra.sort_guard = G().scene.sg.n_fpairs != 0 ? 1 : 0;
