@@ -200,7 +200,9 @@ def shares_run(ctx, scenes, torch, dev, frames=3):
         def timed(G, n):
             kw = dict(spp_begin=0) if kind == "spp" else dict(band_first=0, band_stride=G)
             s = spp // G if kind == "spp" else spp
-            ctx.render_into(W, H, acc, min(s, 8), depth, seed=0xC0FFEE, **kw)      # warm-up of this shape
+            # warm-up of this shape (c3: the same samples, so that the colour buffer is there; c5 keeps its buffer from share to share
+            # once the first two calls have grown it, and its G = 8 share fits what they left)
+            ctx.render_into(W, H, acc, s if name == "c3" else min(s, 8), depth, seed=0xC0FFEE, **kw)
             torch.cuda.synchronize(dev)
             t0 = time.perf_counter()
             k_ms = 0.0
