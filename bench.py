@@ -193,8 +193,8 @@ def shares_run(ctx, scenes, torch, dev, frames=3):
         ctx.upload_scene(scenes.get_scene(wl["scene"], **wl["kw"]))
         acc = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
         bytes_acc = W * H * 16
-        # a rank of a tile-split job owns its GPU: the colour buffer of the frame's end may hold the whole share (1 KiB per tile and
-        # sample: 16.2 GB for the 1/8 share at 1024 spp), which makes the share parallel over samples too (rt_set_tail_limit)
+        # a rank of a tile-split job owns its GPU: the colour buffer of the frame's end may hold the whole share (768 B per tile and
+        # sample: 12.2 GB for the 1/8 share at 1024 spp), which makes the share parallel over samples too (rt_set_tail_limit)
         ctx.set_tail_limit(TILE_SPLIT_TAIL_MB if kind == "tile" else DEFAULT_TAIL_MB)
 
         def timed(G, n):

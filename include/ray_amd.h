@@ -126,15 +126,15 @@ int rt_reset_stream(void);
  * Device memory this needs: 4 bytes per 8x8 tile of the frame (grown on demand, freed by rt_shutdown).                 */
 int rt_set_sample_slices(int min_samples, int max_slices);
 /* Upper limit (MiB; default 2048, 0 = none) of the colour buffer that rt_render / rt_render_bands keep for the END of a
- * frame (no counterpart in the reference). Up to half of a frame's tiles (all of them on small frames) are rendered last, in units of 8 samples per pixel whose colours (16 bytes each: 1 KiB per tile and
+ * frame (no counterpart in the reference). Up to half of a frame's tiles (all of them on small frames) are rendered last, in units of 8 samples per pixel whose colours (12 bytes each: 768 bytes per tile and
  * sample) go to this buffer and are added in sample order by a second kernel: the same bits as a pixel summed by one
  * thread, but parallel over a pixel's samples too, which is what keeps every lane fed while the frame runs out. The buffer
  * is allocated by the first frame that wants it, grown on demand up to the limit, and released by this call (when it
  * holds more than the new limit), by rt_upload_scene and by rt_shutdown; a device that cannot spare it gets a smaller
- * one or none. Where the limit leaves less than half the buffer a frame would like (1 KiB x tiles x samples: 4K frames of
+ * one or none. Where the limit leaves less than half the buffer a frame would like (768 B x tiles x samples: 4K frames of
  * hundreds of samples), the other tiles are rendered in sample slices (rt_set_sample_slices) instead of as whole pixels.
- * Frames are bit-identical whatever the limit; only their last part is slower with less (4K / 256 spp on MI355X: 381 ms
- * with 4 GiB, 385 with 2, 390 with 1 or none; 1080p / 64 spp frames want 1 GiB).                                   */
+ * Frames are bit-identical whatever the limit; only their last part is slower with less (4K / 256 spp on MI355X: 376 ms
+ * with 4 GiB, 381 with 2, 387 with 1 or none; 1080p / 64 spp frames want 0.8 GiB).                                   */
 int rt_set_tail_limit(int64_t megabytes);
 /* Block-sorted shading, an experiment kept for the record: mode 1 shades the bounces of a block's 256 rays in
  * order of material, so that a wave executes one material's code instead of all of them (plain frames of scenes without triangles,

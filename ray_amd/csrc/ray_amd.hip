@@ -1063,7 +1063,7 @@ struct RenderArgs {
     // above. They come after all of those, as tail_chunks units of tail_chunk samples per pixel whose colours go to `tail` and are
     // summed in sample order by tail_sum_kernel: work that is parallel over a pixel's samples too, for the end of the frame.
     int n_tail_tiles, tail_chunk, tail_chunks, tail_stride;
-    float4* __restrict__ tail;                     // [n_tail_tiles][spp_count][64] colour of sample s of pixel `in` of tail tile t
+    float* __restrict__ tail;                      // [n_tail_tiles][spp_count][64][3] colour (r, g, b: 12 bytes) of sample s of pixel `in` of tail tile t
     unsigned int* __restrict__ tile_state;         // [n_tiles] low byte: slices of the tile that are finished; bit 8 + k: unit (k, tile) came up before
                                                    // slice k - 1 was finished and belongs to whoever finishes it (zeroed before the launch; null when n_slices == 1)
     int sort_guard;                                // SORT kernels: the scene's scans write flag words (a fourth barrier per trip keeps them off the results)
@@ -1431,7 +1431,8 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
                 const V3 colour = unwind_path(st, level, L);
                 const bool tail_px = !PIXELS && slot == kTailSlot;
                 if (tail_px) {
-                    ra.tail[__float_as_uint(wn) + uint32_t(s - ra.spp_begin) * 64u] = make_float4(colour.x, colour.y, colour.z, 0.0f);
+                    float* tc = ra.tail + 3u * size_t(__float_as_uint(wn) + uint32_t(s - ra.spp_begin) * 64u);
+                    tc[0] = colour.x; tc[1] = colour.y; tc[2] = colour.z;
                 } else {
                     sum = sum + colour;                                           // rayview.cpp:83
                     wn += 1.0f;                                                   // (samples summed: exact up to 2^24)
@@ -1515,7 +1516,7 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
 
 // The tail tiles of a frame (render_kernel): one thread per pixel adds the stored colours of its samples in sample order, as
 // the lane that renders a whole pixel does (rayview.cpp:79-84), and writes the accumulator the same way. A wave is one tile:
-// the 64 lanes read 1 KB of consecutive colours per sample.
+// the 64 lanes read 768 bytes of consecutive colours per sample.
 __global__ __launch_bounds__(256) void tail_sum_kernel(RenderArgs ra) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int tt = idx >> 6, in = idx & 63;
@@ -1525,15 +1526,15 @@ __global__ __launch_bounds__(256) void tail_sum_kernel(RenderArgs ra) {
     const int x = (tile % tiles_x) * kTile + (in & 7);
     const int y = ra.y_begin + (ra.band_first + (tile / tiles_x) * ra.band_stride) * kTile + (in >> 3);
     if (!(x < ra.W && y < ra.y_begin + ra.y_count)) return;
-    const float4* __restrict__ c = ra.tail + (size_t(tt) * size_t(ra.spp_count) * 64u + size_t(in));
+    const float* __restrict__ c = ra.tail + 3u * (size_t(tt) * size_t(ra.spp_count) * 64u + size_t(in));
     const uint32_t pix = uint32_t(y) * uint32_t(ra.W) + uint32_t(x);
     V3 sum = v3(0.0f, 0.0f, 0.0f);
     float wn = 0.0f;
     if (ra.flags & RT_RENDER_CONTINUE) { const float4 o = ra.accum[pix]; sum = v3(o.x, o.y, o.z); wn = o.w; }
 #pragma unroll 8
     for (int s = 0; s < ra.spp_count; ++s) {
-        const float4 v = c[size_t(s) * 64u];
-        sum = sum + v3(v.x, v.y, v.z);
+        const float* v = c + size_t(s) * 192u;
+        sum = sum + v3(v[0], v[1], v[2]);
         wn += 1.0f;
     }
     float4 a = make_float4(sum.x, sum.y, sum.z, wn);
@@ -2677,7 +2678,7 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     // Two ways to keep every lane fed until a frame ends, both leaving the bits of a pixel summed by one thread:
     // * the tail (render_kernel): n_tail tiles spread evenly over the frame are kept for its end and rendered in units of 8 samples
     //   per pixel whose colours go through a buffer (16 bytes per sample), parallel over a pixel's samples as well. Measured best
-    //   (tools/tail_sweep.py, round 2): half the frame's tiles, at most four per resident wave; all tiles of small frames (below). That costs 1 KiB per tile and sample: 1 GiB for a 1080p frame of 64 samples, 4 GiB for 16384 tiles of
+    //   (tools/tail_sweep.py, round 2): half the frame's tiles, at most four per resident wave; all tiles of small frames (below). That costs 768 bytes per tile and sample (1 KiB before the colours were stored as three floats): 1 GiB for a 1080p frame of 64 samples, 4 GiB for 16384 tiles of
     //   a 4K frame of 256, 16 GiB at 1024 samples - so it is bounded (rt_set_tail_limit, default 2 GiB);
     // * sample slices (make_slices): where that limit leaves less than half the tail the frame would like, the other tiles are rendered slice by slice through
     //   the accumulator instead of as whole pixels: no memory to speak of, units that shrink towards the frame's end, but a
@@ -2692,7 +2693,7 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
         // samples takes 403 ms with all 16200 tiles in the tail, 1.02 x its share of the whole frame, and 525 ms with half of them)
         const bool all = n_tiles <= 4 * waves || (long long)n_tiles * 64 <= waves * (long long)spp_count;
         long long t = all ? n_tiles : (n_tiles / 2 < 4 * waves ? n_tiles / 2 : 4 * waves);
-        const long long per_tile = (long long)spp_count * 64 * (long long)sizeof(float4);
+        const long long per_tile = (long long)spp_count * 64 * 12;   // three floats per colour
         const long long cap = (G().tail_limit_mb << 20) / per_tile;
         if (t > cap) { tail_short = 2 * cap < t; t = cap; }   // (half the tail it would like still beats slices: 4K / 256 spp 384.8 against 389.9 ms)
         chunks = (spp_count + chunk - 1) / chunk;
@@ -2730,7 +2731,7 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     }
     ra.n_tail_tiles = n_tail; ra.tail_chunk = chunk; ra.tail_chunks = chunks;
     ra.tail_stride = n_tail > 0 ? n_tiles / n_tail : 1;
-    ra.tail = static_cast<float4*>(G().tail);
+    ra.tail = static_cast<float*>(G().tail);
     const size_t queue_bytes = (size_t(n_bulk > 0 ? n_bulk : 1) * sizeof(unsigned int) + 255) / 256 * 256;   // tile_state: one word per tile
     const long long units = (long long)n_bulk * ra.n_slices + (long long)n_tail * chunks;
     const long long want = (units + 3) / 4;
