@@ -510,7 +510,8 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
         const int n_take = all ? cq_len : cq_len / n_here * n_here;
         // few entries: 2, 4 or 8 lanes share an entry, each taking a part of the chunk's words (the mixed 4K frame queues 13 entries
         // per scan: a round in which 51 lanes idle through 16 slab tests would cost what a full one does)
-        const int lshift = n_take * 8 <= n_here ? 3 : (n_take * 4 <= n_here ? 2 : (n_take * 2 <= n_here ? 1 : 0));
+        static_assert(kItemChunkWords == 4 || kItemChunkWords == 8, "a chunk's batches are one 32-bit mask per lane, shared by up to kItemChunkWords lanes");
+        const int lshift = n_take * 8 <= n_here && kItemChunkWords >= 8 ? 3 : (n_take * 4 <= n_here ? 2 : (n_take * 2 <= n_here ? 1 : 0));
         const int per = kItemChunkWords >> lshift;             // words per lane
         for (int base = 0; base < (n_take << lshift); base += n_here) {
             const int u = base + rank_here;
