@@ -2695,7 +2695,8 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
         const bool all = n_tiles <= 4 * waves || (long long)n_tiles * 64 <= waves * (long long)spp_count;
         long long t = all ? n_tiles : (n_tiles / 2 < 4 * waves ? n_tiles / 2 : 4 * waves);
         const long long per_tile = (long long)spp_count * 64 * 12;   // three floats per colour
-        const long long cap = (G().tail_limit_mb << 20) / per_tile;
+        long long cap = (G().tail_limit_mb << 20) / per_tile;
+        if (cap * spp_count * 64 > 0xffffffffll) cap = 0xffffffffll / (spp_count * 64ll);   // (a colour's index in the buffer is 32 bits wide: limits beyond 48 GiB)
         if (t > cap) { tail_short = 2 * cap < t; t = cap; }   // (half the tail it would like still beats slices: 4K / 256 spp 384.8 against 389.9 ms)
         chunks = (spp_count + chunk - 1) / chunk;
         if (t * chunks * 64 > kMaxWorkItems / 2) t = 0;
