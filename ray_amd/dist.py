@@ -57,11 +57,25 @@ def band_rows(H: int, band_first: int, band_stride: int):
     return out
 
 
-def reduce_accumulators(accum, world: int):
-    """spp-split: sum the per-rank accumulators in place on every rank (no-op for one rank)."""
+def reduce_accumulators(accum, world: int, ordered: bool = False):
+    """spp-split: sum the per-rank accumulators in place on every rank (no-op for one rank).
+    ordered=False: one all-reduce; the order of the additions is the collective's (ring or tree, it may change with the
+    library version and the world size), so the low bits of a pixel can differ from run to run of different set-ups.
+    ordered=True ("reduce in a fixed rank order for bit-reproducibility"): one all-gather of the whole
+    accumulators (world times the bytes) and ((a0 + a1) + a2) + ... in rank order on every rank - the same bits on every
+    rank, whatever the collective does, and the bits ray_amd/host/render_multi.cpp produces in one process."""
     if world > 1:
+        import torch
         import torch.distributed as dist
-        dist.all_reduce(accum)
+        if not ordered:
+            dist.all_reduce(accum)
+            return accum
+        mine = accum.contiguous()
+        parts = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(parts.view(-1), mine.view(-1))
+        accum.copy_(parts[0])
+        for r in range(1, world):
+            accum.add_(parts[r])
     return accum
 
 

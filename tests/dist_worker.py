@@ -59,6 +59,7 @@ def main():
                                 y_begin=y0, y_count=yc, spp_begin=p["spp_begin"], accum=part)
                 rays += n
                 acc[y0:y0 + yc] = torch.from_numpy(part[y0:y0 + yc])
+        mine = acc.clone() if split == "spp" else None
         if split == "tile":
             rdist.gather_bands(acc, rank, world)
         else:
@@ -72,6 +73,15 @@ def main():
             good &= np.array_equal(got, full, equal_nan=True)          # disjoint bands: bit-exact on every rank
         else:
             good &= np.allclose(got[..., :3], full[..., :3], rtol=2e-6, atol=1e-6, equal_nan=True)   # (a+b)+(c+d) vs sequential
+        if split == "spp":
+            # the sum in rank order: the same bits on every rank, and those of ((share 0 + share 1) + share 2) ... from the oracle
+            rdist.reduce_accumulators(mine, world, ordered=True)
+            want = None
+            for k in range(world):
+                q = rdist.plan("spp", W, H, spp, k, world)
+                share, _ = O.render(sc, W, H, q["spp_count"], depth, rng_mode=1, seed64=seed, math_mode=1, spp_begin=q["spp_begin"])
+                want = share if want is None else want + share
+            good &= np.array_equal(mine.cpu().numpy().view(np.uint32), want.view(np.uint32))
         if on_device and rank == 0:
             one, rays_one = ctx.render(W, H, spp, depth, seed=seed)     # the same frame from one plain rt_render
             good &= rays_one == rays_full and np.array_equal(one, full, equal_nan=True)
