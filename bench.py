@@ -240,6 +240,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-also", action="store_true", help="skip the short runs of the other workloads (the `also` dict)")
     ap.add_argument("--no-shares", action="store_true", help="skip the per-rank share timings (also.shares)")
+    ap.add_argument("--ordered-reduce", action="store_true", help="N > 1, spp-split: sum the accumulators in rank order (all-gather; bit-reproducible) instead of one all-reduce")
     ap.add_argument("--shading-sort", type=int, default=-1, help="rt_set_shading_sort mode (diagnostics only; default: the library's)")
     args = ap.parse_args()
 
@@ -309,7 +310,7 @@ def main():
         if split == "tile":
             rdist.gather_bands(accum, rank, world)
         else:
-            rdist.reduce_accumulators(accum, world)
+            rdist.reduce_accumulators(accum, world, ordered=args.ordered_reduce)
         return ms
 
     def sync():
