@@ -2117,7 +2117,8 @@ void rt_shutdown(void) {
 
 int rt_device_info(char* buf, int buflen) {
     if (need_ready()) return 1;
-    snprintf(buf, buflen, "%s|%s|%d|%d", G().prop.name, G().prop.gcnArchName, G().prop.multiProcessorCount, G().prop.clockRate / 1000);
+    if (!buf || buflen <= 0) return fail("rt_device_info: no buffer");
+    snprintf(buf, size_t(buflen), "%s|%s|%d|%d", G().prop.name, G().prop.gcnArchName, G().prop.multiProcessorCount, G().prop.clockRate / 1000);
     return 0;
 }
 

@@ -886,6 +886,22 @@ def test_cpp_multi_device_host(split, shares, tmp_path):
         np.testing.assert_allclose(acc[..., :3], oacc[..., :3], rtol=2e-6, atol=1e-6)
 
 
+def test_c_abi_tour_from_plain_cpp():
+    """ray_amd/host/abi_tour.cpp: every entry point of include/ray_amd.h from plain C++ (no Python, no mirror headers) on a scene
+    with every primitive and material kind -- rejected arguments are rejected and leave the context usable; rt_render_noalloc,
+    rt_render_bands, two row ranges, two RT_RENDER_CONTINUE passes, every work-unit setting and the shading sort leave rt_render's
+    bits; pixel lists short and long touch the listed pixels only; RT_RENDER_VERIFY counts no mismatch; the context survives
+    rt_shutdown + rt_init. (tools/asan_run.sh runs the same program against a host-AddressSanitizer build of the library.)"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "ray_amd", "host", "abi_tour")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "abi tour ok" in r.stdout
+
+
 def test_constant_medium_through_the_c_abi(rt):
     """constant_medium (shapes.h:374-455) in hitFromList for caller rays: the medium draws from the ray's own counter
     stream inside the scan, so which rays draw depends on list order; records carry the reference's 'arbitrary' normal
