@@ -562,7 +562,7 @@ __device__ __forceinline__ void scan_triangles(const DevScene& sc, const Ray& r,
     };
     {
         // Which way a scan goes is decided from the chunk boxes (tested wave-uniformly for 32 chunks at a time, a bit per chunk and
-        // lane): a round of the shared form costs about as much as 2.4 chunks of the wave-uniform form (16 slab tests, 768 bytes of
+        // lane): a round of the shared form costs about as much as 2 chunks of the wave-uniform form (16 slab tests, 768 bytes of
         // vector loads in four dependent groups, the pushes), so it is taken when its rounds replace more chunks than that - the
         // mixed 4K frame: 13 (chunk, lane) needs spread over 4.1 chunks per scan - and not when many lanes want the same few
         // chunks - the 9.8k-triangle mesh alone: 88 needs over 4.2 chunks.
