@@ -2680,7 +2680,7 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     // Two ways to keep every lane fed until a frame ends, both leaving the bits of a pixel summed by one thread:
     // * the tail (render_kernel): n_tail tiles spread evenly over the frame are kept for its end and rendered in units of 8 samples
     //   per pixel whose colours go through a buffer (16 bytes per sample), parallel over a pixel's samples as well. Measured best
-    //   (tools/tail_sweep.py, round 2): half the frame's tiles, at most four per resident wave; all tiles of small frames (below). That costs 768 bytes per tile and sample (1 KiB before the colours were stored as three floats): 1 GiB for a 1080p frame of 64 samples, 4 GiB for 16384 tiles of
+    //   (tools/tail_sweep.py, round 2): half the frame's tiles, at most six per resident wave; all tiles of small frames (below). That costs 768 bytes per tile and sample (1 KiB before the colours were stored as three floats): 1 GiB for a 1080p frame of 64 samples, 4 GiB for 16384 tiles of
     //   a 4K frame of 256, 16 GiB at 1024 samples - so it is bounded (rt_set_tail_limit, default 2 GiB);
     // * sample slices (make_slices): where that limit leaves less than half the tail the frame would like, the other tiles are rendered slice by slice through
     //   the accumulator instead of as whole pixels: no memory to speak of, units that shrink towards the frame's end, but a
@@ -2694,11 +2694,15 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
         // whose whole tiles are large against the frame (n_tiles x 64 <= waves x samples: the 1/8 band share of a 4K frame of 1024
         // samples takes 403 ms with all 16200 tiles in the tail, 1.02 x its share of the whole frame, and 525 ms with half of them)
         const bool all = n_tiles <= 4 * waves || (long long)n_tiles * 64 <= waves * (long long)spp_count;
-        long long t = all ? n_tiles : (n_tiles / 2 < 4 * waves ? n_tiles / 2 : 4 * waves);
+        // (six per wave where the limit allows: frames whose tiles differ much in cost - the mixed 4K frame in passes of 32 .. 128 samples -
+        // gain 1 - 2 % over four, the 485-sphere frame loses at most 0.3 %; whether the other tiles are rendered as whole pixels or in
+        // slices is still decided against four per wave, which is what the 256-sample frames were tuned with)
+        const long long t_need = all ? n_tiles : (n_tiles / 2 < 4 * waves ? n_tiles / 2 : 4 * waves);
+        long long t = all ? n_tiles : (n_tiles / 2 < 6 * waves ? n_tiles / 2 : 6 * waves);
         const long long per_tile = (long long)spp_count * 64 * 12;   // three floats per colour
         long long cap = (G().tail_limit_mb << 20) / per_tile;
         if (cap * spp_count * 64 > 0xffffffffll) cap = 0xffffffffll / (spp_count * 64ll);   // (a colour's index in the buffer is 32 bits wide: limits beyond 48 GiB)
-        if (t > cap) { tail_short = 2 * cap < t; t = cap; }   // (half the tail it would like still beats slices: 4K / 256 spp 384.8 against 389.9 ms)
+        if (t > cap) { tail_short = 2 * cap < t_need; t = cap; }   // (half the tail it would like still beats slices: 4K / 256 spp 384.8 against 389.9 ms)
         chunks = (spp_count + chunk - 1) / chunk;
         if (t * chunks * 64 > kMaxWorkItems / 2) t = 0;
         n_tail = int(t);
