@@ -886,6 +886,30 @@ def test_cpp_multi_device_host(split, shares, tmp_path):
         np.testing.assert_allclose(acc[..., :3], oacc[..., :3], rtol=2e-6, atol=1e-6)
 
 
+def test_4k_frame_has_the_same_bits_however_its_end_is_cut(rt):
+    """render_impl's policy for the end of a frame (how many tiles go through the colour buffer -- six per resident wave on a frame
+    of this size --, whole pixels or sample slices for the others) decides HOW the work is cut, never the result: the 485-sphere
+    scene at 3840x2160, 32 samples, with no buffer, the default one and one smaller than the frame would like."""
+    sc = scenes.get_scene("random", half=11)
+    rt.upload_scene(sc)
+    W, H, spp, depth = 3840, 2160, 32, 8
+    acc = rt.alloc(W * H * 16)
+    try:
+        ref = None
+        for mb, slices in ((0, (0, 16)), (2048, (8, 16)), (300, (8, 16)), (100, (3, 5))):
+            rt.set_tail_limit(mb); rt.set_sample_slices(*slices)
+            acc.zero()
+            rt.render_into(W, H, acc, spp, depth, seed=3)
+            got = acc.to_numpy(np.uint32, (H, W, 4)).copy()
+            if ref is None:
+                ref = got
+                assert (got[..., 3].view(np.float32) == spp).all()
+            assert np.array_equal(got, ref), (mb, slices)
+    finally:
+        rt.set_tail_limit(2048); rt.set_sample_slices(8, 16)
+        acc.free()
+
+
 def test_c_abi_tour_from_plain_cpp():
     """ray_amd/host/abi_tour.cpp: every entry point of include/ray_amd.h from plain C++ (no Python, no mirror headers) on a scene
     with every primitive and material kind -- rejected arguments are rejected and leave the context usable; rt_render_noalloc,
