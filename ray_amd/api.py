@@ -139,9 +139,13 @@ class Context:
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
-    def set_tail_limit(self, megabytes: int = 2048):
+    def set_tail_limit(self, megabytes: int = 1536):
         """rt_set_tail_limit: upper limit of the colour buffer for the end of a frame (0 = none); same bits either way."""
         self._check(self.lib.rt_set_tail_limit(megabytes))
+
+    def set_tile_order(self, mode: int = 0):
+        """rt_set_tile_order: 1 = frames of 32 samples and more hand their tiles out in order of cost (measured by their first sample); same bits."""
+        self._check(self.lib.rt_set_tile_order(mode))
 
     def set_shading_sort(self, mode: int = 0):
         """rt_set_shading_sort: 1 = block-sorted shading where its kernel exists (an experiment, measured slower; 0 = default); same bits."""

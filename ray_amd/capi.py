@@ -82,6 +82,7 @@ _PROTOS = {
     "rt_malloc": ([C.POINTER(C.c_void_p), C.c_uint64], C.c_int),
     "rt_free": ([C.c_void_p], C.c_int),
     "rt_set_shading_sort": ([C.c_int], C.c_int),
+    "rt_set_tile_order": ([C.c_int], C.c_int),
     "rt_malloc_host": ([C.POINTER(C.c_void_p), C.c_uint64], C.c_int),
     "rt_free_host": ([C.c_void_p], C.c_int),
     "rt_memcpy_d2h": ([C.c_void_p, C.c_void_p, C.c_uint64], C.c_int),

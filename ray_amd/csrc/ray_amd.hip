@@ -1068,6 +1068,11 @@ struct RenderArgs {
     unsigned int* __restrict__ tile_state;         // [n_tiles] low byte: slices of the tile that are finished; bit 8 + k: unit (k, tile) came up before
                                                    // slice k - 1 was finished and belongs to whoever finishes it (zeroed before the launch; null when n_slices == 1)
     int sort_guard;                                // SORT kernels: the scene's scans write flag words (a fourth barrier per trip keeps them off the results)
+    // Tiles in order of cost (rt_set_tile_order, render_impl): tile_order[b] is the frame tile of bulk unit tile b, tile_order[n_tiles + t]
+    // that of tail tile t (null: the arithmetic order above); tile_cost, in the one-sample pass that measures, receives the rays of
+    // every frame tile's samples.
+    const int* __restrict__ tile_order;
+    unsigned int* __restrict__ tile_cost;
 };
 
 // (x + xi) / float(W) of rayview.cpp:80-81 without the FP32 division sequence: float(double(n) * inv) with inv = RN(1 / double(float(W))).
@@ -1198,7 +1203,8 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
                 const size_t sb = offsetof(RenderKernArgs, ra) + offsetof(RenderArgs, slice_begin) + size_t(k) * sizeof(int);
                 q_s0 = ra.spp_begin + load_kernarg<int>(sb); q_s1 = ra.spp_begin + load_kernarg<int>(sb + sizeof(int));
                 // the b-th tile that is not a tail tile
-                const int ftile = tile < ra.n_tail_tiles * (ra.tail_stride - 1) ? tile + tile / (ra.tail_stride - 1) : tile + ra.n_tail_tiles;
+                int ftile = tile < ra.n_tail_tiles * (ra.tail_stride - 1) ? tile + tile / (ra.tail_stride - 1) : tile + ra.n_tail_tiles;
+                if (ra.tile_order) ftile = ra.tile_order[tile];
                 const int trow = ftile / tiles_x, tcol = ftile - trow * tiles_x;
                 q_x0 = tcol * kTile;
                 q_y0 = ra.y_begin + (ra.band_first + trow * ra.band_stride) * kTile;
@@ -1244,7 +1250,8 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
                             const int tu = unit - bulk_units;
                             const int tt = tu / ra.tail_chunks, ch = tu - tt * ra.tail_chunks;
                             const int tiles_x = (ra.W + kTile - 1) / kTile;
-                            const int ftile = tt * ra.tail_stride + ra.tail_stride - 1;
+                            int ftile = tt * ra.tail_stride + ra.tail_stride - 1;
+                            if (ra.tile_order) ftile = ra.tile_order[ra.n_tiles + tt];
                             const int trow = ftile / tiles_x, tcol = ftile - trow * tiles_x;
                             q_x0 = tcol * kTile;
                             q_y0 = ra.y_begin + (ra.band_first + trow * ra.band_stride) * kTile;
@@ -1429,6 +1436,11 @@ __global__ __launch_bounds__(kBlock, 4) void render_kernel(DevScene sc, DevCamer
             }
             RT_STAMP(5);
             if (done) {
+                if (!PIXELS && ra.tile_cost) {   // (the one-sample pass of rt_set_tile_order: this sample's rays, to its frame tile)
+                    const int tiles_x = (ra.W + kTile - 1) / kTile;
+                    const int trow = (((y - ra.y_begin) >> 3) - ra.band_first) / ra.band_stride;
+                    atomicAdd(ra.tile_cost + (trow * tiles_x + (x >> 3)), uint32_t(level) + 1u);
+                }
                 const V3 colour = unwind_path(st, level, L);
                 const bool tail_px = !PIXELS && slot == kTailSlot;
                 if (tail_px) {
@@ -1523,7 +1535,7 @@ __global__ __launch_bounds__(256) void tail_sum_kernel(RenderArgs ra) {
     const int tt = idx >> 6, in = idx & 63;
     if (tt >= ra.n_tail_tiles) return;
     const int tiles_x = (ra.W + kTile - 1) / kTile;
-    const int tile = tt * ra.tail_stride + ra.tail_stride - 1;
+    const int tile = ra.tile_order ? ra.tile_order[ra.n_tiles + tt] : tt * ra.tail_stride + ra.tail_stride - 1;
     const int x = (tile % tiles_x) * kTile + (in & 7);
     const int y = ra.y_begin + (ra.band_first + (tile / tiles_x) * ra.band_stride) * kTile + (in >> 3);
     if (!(x < ra.W && y < ra.y_begin + ra.y_count)) return;
@@ -1555,6 +1567,23 @@ __global__ void pixel_tile_keys_kernel(int n, int W, int H, int tiles_x, int n_t
     uint32_t k = uint32_t(n_tiles);
     if (uint32_t(p) < uint32_t(W) * uint32_t(H)) { const int y = p / W, x = p - y * W; k = uint32_t((y >> 3) * tiles_x + (x >> 3)); }
     keys[i] = k;
+}
+
+// rt_set_tile_order: 0, 1, 2, ... (the values the radix sort carries along with the tiles' costs)
+__global__ void tile_iota_kernel(int n, int* __restrict__ idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = i;
+}
+// ... and the order render_kernel reads, from the tiles sorted by falling cost: every stride-th of them (n_tail in all) is a tail tile,
+// as every stride-th tile of the frame is without the sort, so that the tail keeps its share of the frame's work; the others are
+// the bulk tiles, heaviest first. order[0 .. n - n_tail): bulk, order[n - n_tail .. n): tail.
+__global__ void tile_arrange_kernel(int n, int n_tail, int stride, const int* __restrict__ sorted, int* __restrict__ order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int q = (i + 1) / stride;
+    if (n_tail > 0 && (i + 1) % stride == 0 && q <= n_tail) { order[n - n_tail + q - 1] = sorted[i]; return; }
+    const int before = i / stride < n_tail ? i / stride : n_tail;   // tail tiles among the sorted positions before this one
+    order[i - before] = sorted[i];
 }
 
 // depth <= 0 or no samples: every sample is black and no ray is traced (calc.cpp:96-97)
@@ -1724,11 +1753,15 @@ struct Context {
     int slice_min = 8, slice_max = kMaxSlices;   // rt_set_sample_slices
     void* tail = nullptr;               // colours of the frame's tail tiles (render_kernel, tail_sum_kernel); grown on demand up to tail_limit_mb,
     size_t tail_bytes = 0;              // released by rt_set_tail_limit / rt_upload_scene / rt_shutdown
-    long long tail_limit_mb = 2048;     // rt_set_tail_limit
+    long long tail_limit_mb = 1536;     // rt_set_tail_limit
     bool slices_always = false;         // RT_SLICES_ALWAYS=1 (tests, tools): sample slices also where the tail has its full size
     int sort_mode = 0;                  // rt_set_shading_sort: 1 = block-sorted shading wherever its kernel exists (measured slower: off by default)
     void* pix_sort = nullptr;           // rt_render_pixels: tile keys in / out, sorted pixel indices, radix-sort workspace (grow-only)
     size_t pix_sort_bytes = 0;
+    int order_mode = 1;                 // rt_set_tile_order: 1 = frames of many samples and thin filler hand their tiles out in order of measured cost (2: every frame of 64 samples and more)
+    void* order_buf = nullptr;          // rays per tile, tile indices, both sorted, the order the kernel reads, radix-sort workspace (grow-only)
+    size_t order_bytes = 0;
+    int phase_launches = 0;             // launches of the measuring pass of such a frame (its time is part of the frame's)
     hipStream_t own_stream = nullptr;   // created by rt_init; `stream` is this one unless rt_set_stream handed in the caller's
     bool pending = false;               // a RT_RENDER_NOWAIT launch whose end event has not been waited for yet
     int pending_launches = 0;
@@ -2007,6 +2040,7 @@ static int init_context(Context& c, int device) {
     HIP_OK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<false, false, 0>, kBlock, 0));
     c.render_blocks_per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
     if (const char* e = getenv("RT_SLICES_ALWAYS")) c.slices_always = atoi(e) != 0;
+    if (const char* e = getenv("RT_TILE_ORDER")) { const int v = atoi(e); if (v >= 0 && v <= 2) c.order_mode = v; }   // tools/: rt_set_tile_order
     if (const char* e = getenv("RT_TAIL_MB")) { const long long v = atoll(e); if (v >= 0) c.tail_limit_mb = v; }
     if (const char* e = getenv("RT_SLICE_MIN")) { const int v = atoi(e); if (v >= 0) c.slice_min = v; }   // tools/: 0 = whole pixels
     c.device = device;
@@ -2020,6 +2054,8 @@ static void destroy_context(Context& c) {
     if (c.stack) (void)hipFree(c.stack);
     if (c.counters) (void)hipFree(c.counters);
     if (c.pix_sort) (void)hipFree(c.pix_sort);
+    if (c.order_buf) (void)hipFree(c.order_buf);
+    c.order_buf = nullptr; c.order_bytes = 0;
     if (c.queue) (void)hipFree(c.queue);
     if (c.tail) (void)hipFree(c.tail);
     if (c.ev0) (void)hipEventDestroy(c.ev0);
@@ -2086,6 +2122,13 @@ int rt_set_sample_slices(int min_samples, int max_slices) {
     if (min_samples < 0 || max_slices < 1) return fail("rt_set_sample_slices: bad arguments %d, %d", min_samples, max_slices);
     G().slice_min = min_samples;
     G().slice_max = max_slices < kMaxSlices ? max_slices : kMaxSlices;
+    return 0;
+}
+
+int rt_set_tile_order(int mode) {
+    if (need_ready()) return 1;
+    if (mode < 0 || mode > 2) return fail("rt_set_tile_order: mode %d outside 0..2", mode);
+    G().order_mode = mode;
     return 0;
 }
 
@@ -2649,8 +2692,37 @@ int rt_trace_rays(int64_t n, const float* d_origin, const float* d_dir, int dept
 
 // scratch_dev: nullptr = the library's own buffers (counter block from rt_init, path stack grown by ensure_stack);
 // otherwise the device address of the file-scope `scratch` array (rt_render_noalloc): no allocation on this path.
-static int render_impl(const char* who, int w, int h, int y_begin, int y_count, int band_first, int band_stride, int tiles_y, int spp_begin,
-                       int spp_count, int depth, uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays, void* scratch_dev = nullptr) {
+// How many of a frame's tiles go through the colour buffer of the frame's end (render_pass has the reasons), and whether that is
+// less than half of what the frame would like (then the other tiles are rendered in sample slices instead of as whole pixels).
+static long long tail_tiles_wanted(long long n_tiles, long long waves, int spp_count, bool* tail_short) {
+    // all tiles: frames of up to four tiles per wave (1280 x 720 at 64 samples: 16.2 against 20.2 ms with half of them), and frames
+    // whose whole tiles are large against the frame (n_tiles x 64 <= waves x samples: the 1/8 band share of a 4K frame of 1024
+    // samples takes 403 ms with all 16200 tiles in the tail, 1.02 x its share of the whole frame, and 525 ms with half of them)
+    const bool all = n_tiles <= 4 * waves || n_tiles * 64 <= waves * (long long)spp_count;
+    // (six per wave where the limit allows: frames whose tiles differ much in cost - the mixed 4K frame in passes of 32 .. 128 samples -
+    // gain 1 - 2 % over four, the 485-sphere frame loses at most 0.3 %; whether the other tiles are rendered as whole pixels or in
+    // slices is still decided against four per wave, which is what the 256-sample frames were tuned with)
+    const long long t_need = all ? n_tiles : (n_tiles / 2 < 4 * waves ? n_tiles / 2 : 4 * waves);
+    long long t = all ? n_tiles : (n_tiles / 2 < 6 * waves ? n_tiles / 2 : 6 * waves);
+    const long long per_tile = (long long)spp_count * 64 * 12;   // three floats per colour
+    long long cap = (G().tail_limit_mb << 20) / per_tile;
+    if (cap * spp_count * 64 > 0xffffffffll) cap = 0xffffffffll / (spp_count * 64ll);   // (a colour's index in the buffer is 32 bits wide: limits beyond 48 GiB)
+    *tail_short = false;
+    if (t > cap) { *tail_short = 2 * cap < t_need; t = cap; }   // (half the tail it would like still beats slices: 4K / 256 spp 384.8 against 389.9 ms)
+    return t;
+}
+
+// phase: 0 = a frame in one pass; 1 / 2 = the measuring pass (one sample per pixel, rays per tile to order_buf) and the rest of a frame
+// whose tiles are handed out in order of cost (render_impl below): one timed region, the first pass neither ends it nor waits.
+struct OrderBufs { unsigned int* cost; int* idx; unsigned int* cost_sorted; int* idx_sorted; int* order; void* tmp; size_t tmp_bytes; };
+static OrderBufs order_bufs(int n_tiles, size_t tmp_bytes) {
+    const size_t arr = (size_t(n_tiles) * 4 + 255) / 256 * 256;
+    char* b = static_cast<char*>(G().order_buf);
+    return OrderBufs{reinterpret_cast<unsigned int*>(b), reinterpret_cast<int*>(b + arr), reinterpret_cast<unsigned int*>(b + 2 * arr),
+                     reinterpret_cast<int*>(b + 3 * arr), reinterpret_cast<int*>(b + 4 * arr), b + 5 * arr, tmp_bytes};
+}
+static int render_pass(const char* who, int w, int h, int y_begin, int y_count, int band_first, int band_stride, int tiles_y, int spp_begin,
+                       int spp_count, int depth, uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays, void* scratch_dev, int phase) {
     if (spp_begin < 0 || spp_count < 0) return fail("%s: bad sample range [%d,+%d)", who, spp_begin, spp_count);
     if (depth < 0 || depth > 128) return fail("%s: depth %d outside 0..128", who, depth);
     if (!d_accum) return fail("%s: null accumulator", who);
@@ -2689,20 +2761,8 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     int chunk = 8, n_tail = 0, chunks = 1;
     bool tail_short = true;             // the tail is smaller than the frame would like (or there is none)
     if (!scratch_dev && G().tail_limit_mb > 0 && spp_count >= 2 * chunk) {
-        tail_short = false;
-        // all tiles: frames of up to four tiles per wave (1280 x 720 at 64 samples: 16.2 against 20.2 ms with half of them), and frames
-        // whose whole tiles are large against the frame (n_tiles x 64 <= waves x samples: the 1/8 band share of a 4K frame of 1024
-        // samples takes 403 ms with all 16200 tiles in the tail, 1.02 x its share of the whole frame, and 525 ms with half of them)
-        const bool all = n_tiles <= 4 * waves || (long long)n_tiles * 64 <= waves * (long long)spp_count;
-        // (six per wave where the limit allows: frames whose tiles differ much in cost - the mixed 4K frame in passes of 32 .. 128 samples -
-        // gain 1 - 2 % over four, the 485-sphere frame loses at most 0.3 %; whether the other tiles are rendered as whole pixels or in
-        // slices is still decided against four per wave, which is what the 256-sample frames were tuned with)
-        const long long t_need = all ? n_tiles : (n_tiles / 2 < 4 * waves ? n_tiles / 2 : 4 * waves);
-        long long t = all ? n_tiles : (n_tiles / 2 < 6 * waves ? n_tiles / 2 : 6 * waves);
         const long long per_tile = (long long)spp_count * 64 * 12;   // three floats per colour
-        long long cap = (G().tail_limit_mb << 20) / per_tile;
-        if (cap * spp_count * 64 > 0xffffffffll) cap = 0xffffffffll / (spp_count * 64ll);   // (a colour's index in the buffer is 32 bits wide: limits beyond 48 GiB)
-        if (t > cap) { tail_short = 2 * cap < t_need; t = cap; }   // (half the tail it would like still beats slices: 4K / 256 spp 384.8 against 389.9 ms)
+        long long t = tail_tiles_wanted(n_tiles, waves, spp_count, &tail_short);
         chunks = (spp_count + chunk - 1) / chunk;
         if (t * chunks * 64 > kMaxWorkItems / 2) t = 0;
         n_tail = int(t);
@@ -2784,7 +2844,15 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     if (ra.n_slices > 1) {   // no slice of any tile is finished, none has been left to another wave
         HIP_OK(hipMemsetAsync(queue, 0, queue_bytes, G().stream));
     }
-    if (begin_timed()) return 1;
+    int extra_launches = 0;
+    if (phase == 1) ra.tile_cost = order_bufs(n_tiles, 0).cost;
+    if (phase != 2 && begin_timed()) return 1;
+    if (phase == 2) {
+        const OrderBufs ob = order_bufs(n_tiles, 0);
+        hipLaunchKernelGGL(tile_arrange_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, G().stream, n_tiles, n_tail, ra.tail_stride, ob.idx_sorted, ob.order);
+        ra.tile_order = ob.order;
+        extra_launches = G().phase_launches + 3;   // (the measuring pass, the sort's kernels counted as one, the index fill, this one)
+    }
     const bool many_rects = G().scene.n_rect >= kRectFlagMin;
     const bool bvh = G().scene.tbvh != nullptr && !many_rects;   // (a scene with many rects AND a triangle BVH takes the flat triangle path)
     const bool chain = ra.n_slices > 1;
@@ -2806,7 +2874,56 @@ static int render_impl(const char* who, int w, int h, int y_begin, int y_count, 
     else { if (chain) RT_LAUNCH(false, false, 0, 0, 0, true); else RT_LAUNCH(false, false, 0, 0, 0, false); }
 #undef RT_LAUNCH
     if (n_tail > 0) hipLaunchKernelGGL(tail_sum_kernel, dim3((n_tail * 64 + 255) / 256), dim3(256), 0, G().stream, ra);
-    return finish_timed(n_tail > 0 ? 2 : 1, (flags & RT_RENDER_NOWAIT) != 0);
+    if (phase == 1) { HIP_OK(hipGetLastError()); G().phase_launches = n_tail > 0 ? 2 : 1; return 0; }
+    return finish_timed((n_tail > 0 ? 2 : 1) + extra_launches, (flags & RT_RENDER_NOWAIT) != 0);
+}
+
+// Tiles in order of cost (rt_set_tile_order(1)). A frame ends when its last unit does, and the units are handed out in
+// the order of the tiles in the image, whatever they cost: the last whole-pixel tiles of a frame of many samples finish anywhere in
+// the time of one expensive tile, and the colour buffer's filler has to cover that. Here the frame's first sample is rendered as a
+// pass of its own, which also counts the rays of every tile; the tiles are sorted by that count (device radix sort, same stream), and
+// the other samples CONTINUE the sums (RT_RENDER_CONTINUE: the bits of one call) with the heaviest tiles first and every
+// tail_stride-th tile of the sorted order as the tail. No sample is rendered twice and none is skipped.
+static int render_impl(const char* who, int w, int h, int y_begin, int y_count, int band_first, int band_stride, int tiles_y, int spp_begin,
+                       int spp_count, int depth, uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays, void* scratch_dev = nullptr) {
+    const long long n_tiles_ll = (long long)((w + kTile - 1) / kTile) * tiles_y;
+    const long long waves = (long long)G().prop.multiProcessorCount * G().render_blocks_per_cu * (kBlock / 64);
+    // Where it pays (measured): calls of 64 samples and more whose filler is thin - under five tail tiles per resident wave,
+    // i.e. 1080p frames and 4K frames whose colour buffer is capped by the limit. Frames with more filler end evenly as they are and
+    // would only pay for the extra pass (the 485-sphere 4K frame at 32 .. 128 samples: + 0.3 .. 0.5 %).
+    // (mode 2, for tests and tools: every call of two samples and more, whatever the frame)
+    const bool always = G().order_mode == 2;
+    bool ordered = G().order_mode > 0 && !scratch_dev && spp_begin >= 0 && spp_count >= (always ? 2 : 64) && depth > 0 && depth <= 128 && d_accum && tiles_y > 0 &&
+                   (flags & (RT_RENDER_VERIFY | RT_RENDER_ACCUMULATE)) == 0u && (always || n_tiles_ll >= 2 * waves) && n_tiles_ll * 64 <= kMaxWorkItems;
+    if (ordered && G().order_mode == 1) {
+        bool tail_short = false;
+        const long long t = G().tail_limit_mb > 0 ? tail_tiles_wanted(n_tiles_ll, waves, spp_count - 1, &tail_short) : 0;
+        ordered = t < 5 * waves;
+    }
+    if (!ordered) return render_pass(who, w, h, y_begin, y_count, band_first, band_stride, tiles_y, spp_begin, spp_count, depth, seed, flags, d_accum, d_rays, scratch_dev, 0);
+    const int n_tiles = int(n_tiles_ll);
+    size_t tmp_bytes = 0;
+    {
+        unsigned int* nokey = nullptr; int* noval = nullptr;
+        HIP_OK(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp_bytes, nokey, nokey, noval, noval, n_tiles, 0, 32, G().stream));
+    }
+    const size_t arr = (size_t(n_tiles) * 4 + 255) / 256 * 256, need = 5 * arr + tmp_bytes;
+    if (need > G().order_bytes) {
+        if (settle()) return 1;
+        HIP_OK(hipStreamSynchronize(G().stream));
+        if (G().order_buf) HIP_OK(hipFree(G().order_buf));
+        G().order_buf = nullptr; G().order_bytes = 0;
+        HIP_OK(hipMalloc(&G().order_buf, need));
+        G().order_bytes = need;
+    }
+    if (settle()) return 1;
+    const OrderBufs ob = order_bufs(n_tiles, tmp_bytes);
+    HIP_OK(hipMemsetAsync(ob.cost, 0, size_t(n_tiles) * 4, G().stream));
+    if (render_pass(who, w, h, y_begin, y_count, band_first, band_stride, tiles_y, spp_begin, 1, depth, seed, flags & ~RT_RENDER_NOWAIT, d_accum, d_rays, nullptr, 1)) return 1;
+    hipLaunchKernelGGL(tile_iota_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, G().stream, n_tiles, ob.idx);
+    HIP_OK(hipcub::DeviceRadixSort::SortPairsDescending(ob.tmp, tmp_bytes, ob.cost, ob.cost_sorted, ob.idx, ob.idx_sorted, n_tiles, 0, 32, G().stream));
+    return render_pass(who, w, h, y_begin, y_count, band_first, band_stride, tiles_y, spp_begin + 1, spp_count - 1, depth, seed, flags | RT_RENDER_CONTINUE, d_accum,
+                       d_rays, nullptr, 2);
 }
 
 int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth, uint64_t seed, uint32_t flags,

@@ -906,8 +906,48 @@ def test_4k_frame_has_the_same_bits_however_its_end_is_cut(rt):
                 assert (got[..., 3].view(np.float32) == spp).all()
             assert np.array_equal(got, ref), (mb, slices)
     finally:
-        rt.set_tail_limit(2048); rt.set_sample_slices(8, 16)
+        rt.set_tail_limit(1536); rt.set_sample_slices(8, 16)
         acc.free()
+
+
+def test_tiles_in_order_of_cost_leave_the_same_bits(rt):
+    """rt_set_tile_order: the first sample as a pass of its own that counts every tile's rays, the tiles sorted by that
+    count, the other samples continued with the heaviest tiles first. Mode 1 (the default) does it where the frame's end has little
+    filler (this 1080p frame of 64 samples), mode 2 everywhere: accumulators, sample counts and ray counts are those of mode 0 --
+    whole frames, interleaved bands, passes that continue one another, a frame without a colour buffer, a small frame."""
+    sc = scenes.builtin_scene()
+    rt.upload_scene(sc)
+    try:
+        for W, H, spp, depth, kw in ((1920, 1080, 64, 10, {}), (1920, 1080, 64, 10, dict(band_first=1, band_stride=2)), (333, 187, 19, 6, {}),
+                                    (1283, 721, 40, 8, dict(tail_mb=0)), (1283, 721, 33, 8, dict(passes=(5, 28)))):
+            kw = dict(kw)
+            tail_mb, passes = kw.pop("tail_mb", 1536), kw.pop("passes", None)
+            rt.set_tail_limit(tail_mb)
+            acc = rt.alloc(W * H * 16)
+            rays = rt.alloc(8)
+            ref = None
+            for mode in (0, 1, 2):
+                rt.set_tile_order(mode)
+                acc.zero(); rays.zero()
+                if passes:
+                    s0 = 0
+                    for i, n in enumerate(passes):
+                        rt.render_into(W, H, acc, n, depth, seed=9, rays=rays, spp_begin=s0, flags=api_flags_continue() if i else 0, **kw)
+                        s0 += n
+                else:
+                    rt.render_into(W, H, acc, spp, depth, seed=9, rays=rays, **kw)
+                got = (acc.to_numpy(np.uint32, (H, W, 4)).copy(), int(rays.to_numpy("uint64", (1,))[0]))
+                if ref is None:
+                    ref = got
+                assert np.array_equal(got[0], ref[0]) and got[1] == ref[1], (W, H, spp, kw, mode)
+            acc.free(); rays.free()
+    finally:
+        rt.set_tile_order(1); rt.set_tail_limit(1536)
+
+
+def api_flags_continue():
+    from ray_amd import api
+    return api.RENDER_CONTINUE
 
 
 def test_c_abi_tour_from_plain_cpp():
@@ -1143,7 +1183,7 @@ def test_sample_slices_give_the_same_frame(rt):
         assert O.same_bits_or_nan(total, oacc)
     finally:
         rt.set_sample_slices(8, 16)
-        rt.set_tail_limit(2048)
+        rt.set_tail_limit(1536)
     # a frame with several tiles per wave: the three ways to render it
     sc2 = scenes.builtin_scene()
     rt.upload_scene(sc2)
@@ -1158,7 +1198,7 @@ def test_sample_slices_give_the_same_frame(rt):
         assert rt.last_kernel_ms()[1] == 1
     finally:
         rt.set_sample_slices(8, 16)
-        rt.set_tail_limit(2048)
+        rt.set_tail_limit(1536)
     assert ra == rb and O.same_bits_or_nan(a, b)
 
 
@@ -1219,7 +1259,7 @@ def test_block_sorted_shading_gives_the_same_frame(rt):
         rt.set_sample_slices(2, 16)
         acc, rays = rt.render(W, H, spp, depth, seed=5)
         assert rt.last_kernel_ms()[1] == 1 and rays == orays and O.same_bits_or_nan(acc, oacc)
-        rt.set_tail_limit(2048)
+        rt.set_tail_limit(1536)
         rt.set_sample_slices(8, 16)
         nacc, _ = O.render(sc, W, H, 2, depth, rng_mode=1, seed64=5, math_mode=1, n_threads=8, flags=api.RENDER_NORMALS)
         acc, _ = rt.render(W, H, 2, depth, seed=5, flags=api.RENDER_NORMALS)
@@ -1237,7 +1277,7 @@ def test_block_sorted_shading_gives_the_same_frame(rt):
             assert got[0][1] == got[1][1] and np.array_equal(got[0][0], got[1][0]), name
     finally:
         rt.set_shading_sort(0)
-        rt.set_tail_limit(2048)
+        rt.set_tail_limit(1536)
         rt.set_sample_slices(8, 16)
 
 

@@ -85,8 +85,9 @@ for i in range(n_cases):
     if os.environ.get("RT_FUZZ_UNITS") == "1":   # round 3: how the frame's work is cut up -- colour buffer of the frame's end, sample slices, shading sort
         spp = int(rng.choice([1, 3, 8, 16, 17, 24, 40]))
         mb, smin, smax, sort = int(rng.choice([0, 1, 2048])), int(rng.choice([0, 1, 3, 8])), int(rng.choice([2, 5, 16])), int(rng.integers(0, 2))
-        ctx.set_tail_limit(mb); ctx.set_sample_slices(smin, smax); ctx.set_shading_sort(sort)
-        how = f" tail {mb} MiB slices ({smin}, {smax}) sort {sort}"
+        order = int(rng.choice([0, 1, 2, 2]))
+        ctx.set_tail_limit(mb); ctx.set_sample_slices(smin, smax); ctx.set_shading_sort(sort); ctx.set_tile_order(order)
+        how = f" tail {mb} MiB slices ({smin}, {smax}) sort {sort} order {order}"
     seed = int(rng.integers(0, 2 ** 62))
     ctx.upload_scene(sc)
     acc, rays = ctx.render(W, H, spp, depth, seed=seed)
