@@ -141,6 +141,14 @@ int main() {
     OK(rt_set_sample_slices(8, 16));
     MUST_FAIL(rt_set_sample_slices(-1, 4));
     MUST_FAIL(rt_set_tail_limit(-5));
+    for (int mode : {0, 2, 1}) {   // tiles in image order, in order of cost for every call, the default rule
+        OK(rt_set_tile_order(mode));
+        OK(rt_render(W, H, 0, H, 0, SPP, DEPTH, 5, 0, a1, nullptr));
+        if (!same("rt_render, tile order")) return 1;
+        OK(rt_render_bands(W, H, 1, 2, 0, SPP, DEPTH, 5, 0, a1, nullptr));   // (rows of the other bands keep what they hold)
+        if (!same("rt_render_bands, tile order")) return 1;
+    }
+    MUST_FAIL(rt_set_tile_order(3));
     OK(rt_set_shading_sort(1));
     OK(rt_render(W, H, 0, H, 0, SPP, DEPTH, 5, 0, a1, nullptr));
     if (!same("rt_render, shading sort")) return 1;
