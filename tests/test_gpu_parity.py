@@ -919,9 +919,9 @@ def test_tiles_in_order_of_cost_leave_the_same_bits(rt):
     rt.upload_scene(sc)
     try:
         for W, H, spp, depth, kw in ((1920, 1080, 64, 10, {}), (1920, 1080, 64, 10, dict(band_first=1, band_stride=2)), (333, 187, 19, 6, {}),
-                                    (1283, 721, 40, 8, dict(tail_mb=0)), (1283, 721, 33, 8, dict(passes=(5, 28)))):
+                                    (1283, 721, 40, 8, dict(tail_mb=0)), (1283, 721, 33, 8, dict(passes=(5, 28))), (640, 360, 24, 8, dict(nowait=True))):
             kw = dict(kw)
-            tail_mb, passes = kw.pop("tail_mb", 1536), kw.pop("passes", None)
+            tail_mb, passes, nowait = kw.pop("tail_mb", 1536), kw.pop("passes", None), kw.pop("nowait", False)
             rt.set_tail_limit(tail_mb)
             acc = rt.alloc(W * H * 16)
             rays = rt.alloc(8)
@@ -934,6 +934,11 @@ def test_tiles_in_order_of_cost_leave_the_same_bits(rt):
                     for i, n in enumerate(passes):
                         rt.render_into(W, H, acc, n, depth, seed=9, rays=rays, spp_begin=s0, flags=api_flags_continue() if i else 0, **kw)
                         s0 += n
+                elif nowait:                       # RT_RENDER_NOWAIT: the call returns with both launches queued; rt_sync waits
+                    from ray_amd import api
+                    rt.render_into(W, H, acc, spp, depth, seed=9, rays=rays, flags=api.RENDER_NOWAIT)
+                    rt.sync()
+                    assert rt.last_kernel_ms()[0] > 0
                 else:
                     rt.render_into(W, H, acc, spp, depth, seed=9, rays=rays, **kw)
                 got = (acc.to_numpy(np.uint32, (H, W, 4)).copy(), int(rays.to_numpy("uint64", (1,))[0]))
