@@ -5,6 +5,7 @@
 #   clang++ -std=c++17 -O1 -g -fsanitize=address -I ray_amd/host -I include ray_amd/host/<name>.cpp -L tools/asan -lray_amd -Wl,-rpath,'$ORIGIN'
 # against it. In the box's scratch copy of the tree
 # the callers take the place of the product's, and the GPU tests that start them run as they are.
+# (.gpurunignore lists ./tools/asan so that ordinary GPU calls do not carry the 40 MB: take that line out for the call that runs this.)
 #   bash tools/asan_run.sh <log> [tools/asan | tools/ubsan]      (tools/ubsan: the same with -fsanitize=undefined -fno-sanitize-recover=undefined)
 set -u
 root=${GRAFT_REPO_ROOT:-$(pwd)}
