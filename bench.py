@@ -175,7 +175,7 @@ def quick_run(ctx, api, scenes, torch, dev, name, frames=1):
     return out
 
 
-DEFAULT_TAIL_MB, TILE_SPLIT_TAIL_MB = 1536, 20480   # rt_set_tail_limit: the library's default; what a rank of a tile-split job (owning its GPU) allows
+DEFAULT_TAIL_MB, TILE_SPLIT_TAIL_MB = 1400, 20480   # rt_set_tail_limit: the library's default; what a rank of a tile-split job (owning its GPU) allows
 XGMI_LINK_GBPS = 153.0   # one xGMI link of an MI355X (7 per GPU); a ring collective is bound by one link
 
 
@@ -366,7 +366,7 @@ def main():
                                    "sample order: 0.1 % of the time, DESIGN.md 4.5b)",
                          "kernel_ms": round(k_ms, 3), "flops_per_ray": fpr,
                          "traffic_note": "the accumulator is 16 B per pixel; the rest of `traffic` is the colour buffer of the frame's end "
-                                         "(bounded by rt_set_tail_limit, default 1.5 GiB), written and read once, and the HBM part of the path "
+                                         "(bounded by rt_set_tail_limit, default 1400 MiB), written and read once, and the HBM part of the path "
                                          "stack beyond six bounces (profiles/traffic.json): < 1 % of HBM bandwidth",
                          "accounting": "algorithmic (SURVEY 8d): closest-hit scans x primitives x flops of the reference's test; "
                                        "the box hierarchy and the packed filter answer most tests without evaluating them",

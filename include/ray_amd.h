@@ -125,16 +125,16 @@ int rt_reset_stream(void);
  * min_samples = 0: whole pixels only. max_slices: at most that many slices per call (1..16, default 16).
  * Device memory this needs: 4 bytes per 8x8 tile of the frame (grown on demand, freed by rt_shutdown).                 */
 int rt_set_sample_slices(int min_samples, int max_slices);
-/* Upper limit (MiB; default 1536, 0 = none) of the colour buffer that rt_render / rt_render_bands keep for the END of a
+/* Upper limit (MiB; default 1400, 0 = none) of the colour buffer that rt_render / rt_render_bands keep for the END of a
  * frame (no counterpart in the reference). Up to half of a frame's tiles (all of them on small frames) are rendered last, in units of 8 samples per pixel whose colours (12 bytes each: 768 bytes per tile and
  * sample) go to this buffer and are added in sample order by a second kernel: the same bits as a pixel summed by one
  * thread, but parallel over a pixel's samples too, which is what keeps every lane fed while the frame runs out. The buffer
  * is allocated by the first frame that wants it, grown on demand up to the limit, and released by this call (when it
  * holds more than the new limit), by rt_upload_scene and by rt_shutdown; a device that cannot spare it gets a smaller
- * one or none. Where the limit leaves less than half the buffer a frame would like (768 B x tiles x samples: 4K frames of
+ * one or none. Where the limit leaves less than 4 / 9 of the buffer a frame would like (768 B x tiles x samples: 4K frames of
  * hundreds of samples), the other tiles are rendered in sample slices (rt_set_sample_slices) instead of as whole pixels.
  * Frames are bit-identical whatever the limit; only their last part is slower with less (4K / 256 spp on MI355X, tiles in order
- * of cost (rt_set_tile_order, the default): 378.5 - 379.5 ms with 1.5 or 2 GiB, 389 with 1 GiB or none; 1080p / 64 spp frames want 0.8 GiB). */
+ * of cost (rt_set_tile_order, the default): 378.5 - 379.5 ms with 1400 MiB .. 2 GiB, 389 with 1344 MiB and less; 1080p / 64 spp frames want 0.8 GiB). */
 int rt_set_tail_limit(int64_t megabytes);
 /* Tiles in order of cost (no counterpart in the reference). mode 1 (the default): rt_render / rt_render_bands calls of 64
  * samples and more whose frame has little filler for its end (under five tiles per resident wave in the colour buffer: 1080p frames, 4K
@@ -213,7 +213,7 @@ int rt_hit_rays(int64_t n, const float* d_origin, const float* d_dir, double t_m
  * Device memory the call keeps in the context (grown on demand, freed by rt_shutdown): the path stack beyond
  * six bounces (16 bytes x (depth - 6) per resident thread), 4 bytes per 8x8 tile of the frame for the order
  * between a pixel's sample slices (rt_set_sample_slices), and for spp_count >= 16 the colour buffer of the frame's
- * end, at most 1.5 GiB unless rt_set_tail_limit says otherwise; 20 bytes per tile and a sort workspace for rt_set_tile_order. */
+ * end, at most 1400 MiB unless rt_set_tail_limit says otherwise; 20 bytes per tile and a sort workspace for rt_set_tile_order. */
 int rt_render(int w, int h, int y_begin, int y_count, int spp_begin, int spp_count, int depth,
               uint64_t seed, uint32_t flags, float* d_accum, uint64_t* d_rays);
 

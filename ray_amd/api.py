@@ -139,7 +139,7 @@ class Context:
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
-    def set_tail_limit(self, megabytes: int = 1536):
+    def set_tail_limit(self, megabytes: int = 1400):
         """rt_set_tail_limit: upper limit of the colour buffer for the end of a frame (0 = none); same bits either way."""
         self._check(self.lib.rt_set_tail_limit(megabytes))
 

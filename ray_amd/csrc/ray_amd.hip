@@ -1753,7 +1753,7 @@ struct Context {
     int slice_min = 8, slice_max = kMaxSlices;   // rt_set_sample_slices
     void* tail = nullptr;               // colours of the frame's tail tiles (render_kernel, tail_sum_kernel); grown on demand up to tail_limit_mb,
     size_t tail_bytes = 0;              // released by rt_set_tail_limit / rt_upload_scene / rt_shutdown
-    long long tail_limit_mb = 1536;     // rt_set_tail_limit
+    long long tail_limit_mb = 1400;     // rt_set_tail_limit
     bool slices_always = false;         // RT_SLICES_ALWAYS=1 (tests, tools): sample slices also where the tail has its full size
     int sort_mode = 0;                  // rt_set_shading_sort: 1 = block-sorted shading wherever its kernel exists (measured slower: off by default)
     void* pix_sort = nullptr;           // rt_render_pixels: tile keys in / out, sorted pixel indices, radix-sort workspace (grow-only)
@@ -2708,7 +2708,9 @@ static long long tail_tiles_wanted(long long n_tiles, long long waves, int spp_c
     long long cap = (G().tail_limit_mb << 20) / per_tile;
     if (cap * spp_count * 64 > 0xffffffffll) cap = 0xffffffffll / (spp_count * 64ll);   // (a colour's index in the buffer is 32 bits wide: limits beyond 48 GiB)
     *tail_short = false;
-    if (t > cap) { *tail_short = 2 * cap < t_need; t = cap; }   // (half the tail it would like still beats slices: 4K / 256 spp 384.8 against 389.9 ms)
+    // (4 / 9 of the tail it would like still beats slices: 4K / 256 spp in order of cost 378.9 ms with 1400 MiB as with 1536, 389.3 in slices
+    // with 1344; the mixed frame at 1 024 samples per call is better off in slices below that)
+    if (t > cap) { *tail_short = 9 * cap < 4 * t_need; t = cap; }
     return t;
 }
 

@@ -137,7 +137,7 @@ int main() {
         OK(rt_render(W, H, 0, H, 0, SPP, DEPTH, 5, 0, a1, nullptr));
         if (!same("rt_render with other work units")) return 1;
     }
-    OK(rt_set_tail_limit(1536));
+    OK(rt_set_tail_limit(1400));
     OK(rt_set_sample_slices(8, 16));
     MUST_FAIL(rt_set_sample_slices(-1, 4));
     MUST_FAIL(rt_set_tail_limit(-5));

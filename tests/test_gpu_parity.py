@@ -906,7 +906,7 @@ def test_4k_frame_has_the_same_bits_however_its_end_is_cut(rt):
                 assert (got[..., 3].view(np.float32) == spp).all()
             assert np.array_equal(got, ref), (mb, slices)
     finally:
-        rt.set_tail_limit(1536); rt.set_sample_slices(8, 16)
+        rt.set_tail_limit(1400); rt.set_sample_slices(8, 16)
         acc.free()
 
 
@@ -921,7 +921,7 @@ def test_tiles_in_order_of_cost_leave_the_same_bits(rt):
         for W, H, spp, depth, kw in ((1920, 1080, 64, 10, {}), (1920, 1080, 64, 10, dict(band_first=1, band_stride=2)), (333, 187, 19, 6, {}),
                                     (1283, 721, 40, 8, dict(tail_mb=0)), (1283, 721, 33, 8, dict(passes=(5, 28))), (640, 360, 24, 8, dict(nowait=True))):
             kw = dict(kw)
-            tail_mb, passes, nowait = kw.pop("tail_mb", 1536), kw.pop("passes", None), kw.pop("nowait", False)
+            tail_mb, passes, nowait = kw.pop("tail_mb", 1400), kw.pop("passes", None), kw.pop("nowait", False)
             rt.set_tail_limit(tail_mb)
             acc = rt.alloc(W * H * 16)
             rays = rt.alloc(8)
@@ -947,7 +947,7 @@ def test_tiles_in_order_of_cost_leave_the_same_bits(rt):
                 assert np.array_equal(got[0], ref[0]) and got[1] == ref[1], (W, H, spp, kw, mode)
             acc.free(); rays.free()
     finally:
-        rt.set_tile_order(1); rt.set_tail_limit(1536)
+        rt.set_tile_order(1); rt.set_tail_limit(1400)
 
 
 def api_flags_continue():
@@ -1188,7 +1188,7 @@ def test_sample_slices_give_the_same_frame(rt):
         assert O.same_bits_or_nan(total, oacc)
     finally:
         rt.set_sample_slices(8, 16)
-        rt.set_tail_limit(1536)
+        rt.set_tail_limit(1400)
     # a frame with several tiles per wave: the three ways to render it
     sc2 = scenes.builtin_scene()
     rt.upload_scene(sc2)
@@ -1203,7 +1203,7 @@ def test_sample_slices_give_the_same_frame(rt):
         assert rt.last_kernel_ms()[1] == 1
     finally:
         rt.set_sample_slices(8, 16)
-        rt.set_tail_limit(1536)
+        rt.set_tail_limit(1400)
     assert ra == rb and O.same_bits_or_nan(a, b)
 
 
@@ -1264,7 +1264,7 @@ def test_block_sorted_shading_gives_the_same_frame(rt):
         rt.set_sample_slices(2, 16)
         acc, rays = rt.render(W, H, spp, depth, seed=5)
         assert rt.last_kernel_ms()[1] == 1 and rays == orays and O.same_bits_or_nan(acc, oacc)
-        rt.set_tail_limit(1536)
+        rt.set_tail_limit(1400)
         rt.set_sample_slices(8, 16)
         nacc, _ = O.render(sc, W, H, 2, depth, rng_mode=1, seed64=5, math_mode=1, n_threads=8, flags=api.RENDER_NORMALS)
         acc, _ = rt.render(W, H, 2, depth, seed=5, flags=api.RENDER_NORMALS)
@@ -1282,7 +1282,7 @@ def test_block_sorted_shading_gives_the_same_frame(rt):
             assert got[0][1] == got[1][1] and np.array_equal(got[0][0], got[1][0]), name
     finally:
         rt.set_shading_sort(0)
-        rt.set_tail_limit(1536)
+        rt.set_tail_limit(1400)
         rt.set_sample_slices(8, 16)
 
 

@@ -36,7 +36,7 @@ for w in ("c3", "c2", "box", "c4", "c5"):
                       "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/prof.sh), render_kernel + tail_sum_kernel, summed over "
                               "the launches / their number; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; source profiles/%s_%s_summary.txt. "
                               "Algorithmic = the float4 accumulator. The rest is the colour buffer of the frame's end (DESIGN.md 4.5b / 4.5d, bounded by "
-                              "rt_set_tail_limit, default 1.5 GiB), written once by render_kernel in scattered 12-byte stores (partial lines: more write "
+                              "rt_set_tail_limit, default 1400 MiB), written once by render_kernel in scattered 12-byte stores (partial lines: more write "
                               "traffic than bytes) and read once by tail_sum_kernel, plus, where a frame is rendered in sample slices, one read and one "
                               "write-through store of the accumulator per slice" % (rnd, w)}
 json.dump(pmc_all, open(os.path.join(ROOT, "profiles", f"{rnd}_pmc.json"), "w"), indent=1)

@@ -27,5 +27,5 @@ for name in (sys.argv[1:] or ["c2", "c4", "box"]):
         n = int(rays.to_numpy("uint64", (1,))[0])
         print(f"{name} {W}x{H} spp={spp} tail limit {mb} MiB: {best:.2f} ms, {n / best / 1e3:.0f} Mrays/s", flush=True)
     ctx.set_sample_slices(8, 16)
-    ctx.set_tail_limit(1536)
+    ctx.set_tail_limit(1400)
 ctx.close()
